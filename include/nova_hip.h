@@ -1,0 +1,183 @@
+/*
+ * nova_hip.h — C ABI of libnova_hip.so, the MI355X (gfx950) implementation of NOVA's
+ * autoregressive point-set generation hot path.
+ *
+ * The reference (zailaiyiwan123/NOVA_pointcloud, `diffnext`) is pure Python and has no FFI of its
+ * own; its kernel boundary is "whatever torch op a module's forward() calls". Each entry point
+ * below therefore replaces a group of torch calls, cited as reference file:line (paths relative
+ * to the reference's repository root). The drop-in `diffnext` package shipped in
+ * nova_pointcloud_amd/diffnext binds these through ctypes (see INTEGRATION.md for the stub a
+ * maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C: raw device pointers + sizes; no torch / HIP types in signatures. `stream` is a
+ *     hipStream_t passed as void* (NULL = the legacy default stream). All work is enqueued on that
+ *     stream; nothing synchronises, allocates or frees; buffers are caller-owned.
+ *   - every function returns 0 on success or a negative nova_status; nova_last_error() returns a
+ *     thread-local message for the last failure. Nothing throws.
+ *   - dtype: storage type of activations and GEMM weights (NOVA_F32 = parity mode on exact-f32
+ *     MFMA, NOVA_BF16 = throughput mode on bf16 MFMA). Biases, LayerNorm affine parameters, RoPE
+ *     tables, point coordinates, timesteps and sigmas are always float32; token ids are int64
+ *     (torch.long, as the reference's pred_ids / prev_ids).
+ *   - row-major everywhere; a "row" is one token's feature vector.
+ */
+#ifndef NOVA_HIP_H_
+#define NOVA_HIP_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NOVA_HIP_VERSION 100 /* 0.1.0 */
+
+typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1 } nova_dtype;
+typedef enum { NOVA_ACT_NONE = 0, NOVA_ACT_GELU_ERF = 1, NOVA_ACT_SILU = 2 } nova_act;
+typedef enum {
+  NOVA_OK = 0,
+  NOVA_ERR_ARG = -1,    /* bad enum / null pointer */
+  NOVA_ERR_SHAPE = -2,  /* shape not supported by the built kernels */
+  NOVA_ERR_LAUNCH = -3, /* HIP launch error */
+  NOVA_ERR_DEVICE = -4  /* no gfx950 device */
+} nova_status;
+
+int nova_version(void);
+const char* nova_last_error(void);
+/* 0 when a gfx950 device is current, NOVA_ERR_DEVICE otherwise (checked once by the loader). */
+int nova_check_device(void);
+
+/* ---- projection GEMM -----------------------------------------------------------------------
+ * out[M,N] = act(A[M,K] * W[N,K]^T + bias[N])        W in nn.Linear layout.
+ * Replaces nn.Linear (+ nn.GELU() / nn.SiLU()) at vision_transformer.py:33-38 (MLP.fc1/fc2),
+ * :64 (Attention.proj), diffusion_mlp.py:31-36 (Projector), normalization.py:28,35
+ * (AdaLayerNormZero.proj), embeddings.py:174,203-206 (TextEmbed.proj).
+ * Needs N % 128 == 0 and K % (128 / sizeof(dtype)) == 0; any M >= 0. */
+int nova_gemm_bias_act(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
+                       int dtype, void* stream);
+
+/* ---- fused QKV projection + 3-D RoPE -------------------------------------------------------
+ * qkv[S*L, 3D] = x[S*L, D] * Wqkv^T + b, then q and k (columns [0, 2D)) rotated pairwise with
+ * rope[(s % rope_batch), l, pair] = (cos, sin). rope == NULL: no rotation (abs-PE models).
+ * Replaces vision_transformer.py:52-54 (qkv Linear, view/permute/unbind, pe_func on q and k) and
+ * embeddings.py:36-43 (RotaryEmbed3D.ApplyFunc). The head split is never materialised: the
+ * attention kernel reads q/k/v in place from this buffer. */
+int nova_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L, int D,
+                  int heads, int rope_batch, int dtype, void* stream);
+
+/* rope[nb, pad + n_tok, hd/2, 2] from integer grid positions (embeddings.py:59-67 get_func):
+ * pos [n_pos,3] (t,h,w); ids [nb,n_tok] int64 gathers token -> position (NULL: identity);
+ * the first `pad` rows (condition prefix) sit at position 0; inv_freq [hd/2] = 1 / theta^scale
+ * laid out axis t, h, w (embeddings.py:48-50,63-64). */
+int nova_rope_table(const float* pos, const long long* ids, float* rope, int nb, int pad, int n_tok, int n_pos, int hd,
+                    const float* inv_freq, void* stream);
+
+/* ---- attention ------------------------------------------------------------------------------
+ * o[s, i, h, :] = softmax_j(q[s,i,h,:] . k[s,j,h,:] * scale) v[s,j,h,:], non-causal, no mask.
+ * Element (s, l, head, c) of q lives at q + (s*Lq + l)*q_row_stride + head*head_dim + c (same
+ * for k/v with Lk / kv_row_stride, o with o_row_stride); strides in elements, 16-byte multiples.
+ * Replaces F.scaled_dot_product_attention at vision_transformer.py:63 and the
+ * transpose(1,2).flatten(2) merge at :64. head_dim 64 is built. */
+int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int head_dim,
+                  long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, void* stream);
+
+/* ---- LayerNorm family -----------------------------------------------------------------------
+ * y = LN(in[gather ? gather[r] : r]; eps) [* gamma + beta] [* (1 + mod[r, scale_off..]) +
+ * mod[r, shift_off..]] [* mod[r, gate_off..]] [+ res[r]] -> out[r]. Offsets < 0 disable a term.
+ * Replaces: Block post-norm residual `norm(attn(x)).add_(x)` vision_transformer.py:78-82,91-92;
+ * AdaLayerNormZero.forward normalization.py:34-36; DiffusionBlock `norm2(proj(h)).mul(gate)
+ * .add_(x)` diffusion_mlp.py:52-53; final encoder norm vision_transformer.py:146 fused with the
+ * pred_ids row gather of diffusion_mlp.py:93; TextEmbed.norm embeddings.py:203-206. */
+int nova_row_norm(const void* in, void* out, const float* gamma, const float* beta, const void* mod, long mod_ld,
+                  int scale_off, int shift_off, int gate_off, const void* res, const int* gather, long rows, int D,
+                  float eps, int dtype, void* stream);
+
+/* ---- token plumbing of the masked-autoregressive encoder ------------------------------------
+ * z0 = MaskEmbed(PatchEmbed(canvas)) (+ abs-PE): embeddings.py:160-166,272-274,90-91.
+ * canvas [B,N,P] f32 patchified points, mask [B,N] f32 (1 = unknown), w [D,P] patchified order. */
+int nova_embed_canvas(const float* canvas, const float* mask, const void* w, const float* bias, const void* mask_token,
+                      const void* pos_embed, void* z0, int B, int N, int P, int D, int dtype, void* stream);
+/* x[s] = cat(prefix[s] (Lp rows), tokens[s % B][ids]) : vision_transformer.py:133-136 (gather by
+ * prev_ids + torch.cat). ids NULL = all n_sel tokens in order. tok_batch_rows 0 = shared tokens. */
+int nova_build_sequence(const void* prefix, long prefix_seq_rows, const void* tokens, long tok_batch_rows,
+                        const long long* ids, void* x, int S, int B, int Lp, int n_sel, int D, int dtype, void* stream);
+/* x2[s][Lp + ids[s % B][j]] = x1[s][Lp + j] : x_masked.scatter(1, prev_ids, x) vision_transformer.py:141-143 */
+int nova_scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B, int Lp, int N, int n_prev, int D,
+                        int dtype, void* stream);
+
+/* ---- diffusion-MLP glue ----------------------------------------------------------------------
+ * silu(a + rowvec): the SiLU in front of every AdaLN projection with z = cond + time
+ * (normalization.py:35, diffusion_mlp.py:73-75). rowvec may be NULL. */
+int nova_silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, void* stream);
+/* sinusoidal timestep features [n, freq_dim] = [cos(t f) ; sin(t f)] : diffusion_mlp.py:65-71 */
+int nova_timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, void* stream);
+/* u[s, j] = W x[s % B, j] + b for the n tokens being denoised: diffusion_mlp.py:89-92 */
+int nova_patch_embed_rows(const float* x, const void* w, const float* bias, void* out, int S, int B, int n, int P, int D,
+                          int dtype, void* stream);
+/* head Linear + CFG combine + flow-matching Euler step on x [B,n,P] f32 in place:
+ * diffusion_mlp.py:98, guidance_scaler.py:86-87, scheduling_cfm.py:134-136. h = [2B*n, D]
+ * (cond rows then uncond rows) when cfg != 0, [B*n, D] otherwise. */
+int nova_head_cfg_euler(const void* h, const void* w, const float* bias, float* x, int B, int n, int P, int D,
+                        float guidance, int cfg, float dt, int dtype, void* stream);
+
+/* ---- composite entry points (what the AR loop actually calls) --------------------------------
+ * One ViT block's parameters (reference state_dict names in comments). GEMM weights in `dtype`,
+ * everything else f32. */
+typedef struct {
+  const void* qkv_w;    /* attn.qkv.weight [3D, D] */
+  const float* qkv_b;   /* attn.qkv.bias   [3D]    */
+  const void* proj_w;   /* attn.proj.weight [D, D] */
+  const float* proj_b;
+  const float* norm1_w; /* norm1.weight [D] */
+  const float* norm1_b;
+  const void* fc1_w;    /* mlp.fc1.weight [4D, D] */
+  const float* fc1_b;
+  const void* fc2_w;    /* mlp.fc2.weight [D, 4D] */
+  const float* fc2_b;
+  const float* norm2_w;
+  const float* norm2_b;
+} nova_vit_block;
+
+/* x[S*L, D] <- blocks[nblocks-1](...blocks[0](x)) in place, post-norm residual blocks with fused
+ * QKV+RoPE, flash attention, GELU MLP. Replaces the `for blk in self.blocks[...]` loops of
+ * VisionTransformer.forward (vision_transformer.py:137-138,144-145) and Block.forward (:89-92).
+ * Workspaces: ws_qkv [S*L, 3D], ws_a [S*L, D], ws_b [S*L, D], ws_h [S*L, hidden] in `dtype`. */
+int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
+                            int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
+                            void* ws_h, int dtype, void* stream);
+
+typedef struct {
+  const void* fc1_w;  /* blocks.i.proj.fc1.weight [D, D] */
+  const float* fc1_b;
+  const void* fc2_w;  /* blocks.i.proj.fc2.weight [D, D] */
+  const float* fc2_b;
+  const float* norm2_w; /* blocks.i.norm2 */
+  const float* norm2_b;
+} nova_mlp_block;
+
+typedef struct {
+  int depth;              /* number of DiffusionBlocks (6) */
+  const nova_mlp_block* blocks;
+  const void* adaln_w;    /* cat(blocks.i.norm1.proj.weight (3D each), norm.proj.weight (2D)) [(3*depth+2)D, D] */
+  const float* adaln_b;   /* same concatenation of the biases */
+  const void* patch_w;    /* patch_embed.proj.weight as [D, P] in patchified (i, j, c) order */
+  const float* patch_b;
+  const void* head_w;     /* head.weight [P, D] */
+  const float* head_b;
+} nova_decoder;
+
+/* All `steps` flow-matching Euler steps of Transformer3DModel.denoise (transformer_3d.py:102-113)
+ * for the n tokens predicted in this AR step, launched back to back on `stream`:
+ *   zc    [S*n, D]   condition rows: condition_proj(LN(z)[pred_ids]) (time term NOT yet added)
+ *   temb  [steps, D] timestep_proj(freq(t_i)) per step (diffusion_mlp.py:73)
+ *   x     [B, n, P]  f32, in: noise rows, out: denoised patch vectors
+ *   dt    [steps]    host array sigma_{i+1} - sigma_i (scheduling_cfm.py:134)
+ *   guidance[steps]  host array; entry <= 1 disables CFG for that step (guidance_trunc)
+ * S = 2B when any guidance[i] > 1 (cond rows then uncond rows), else S = B.
+ * Workspaces in `dtype`: ws_a, ws_u, ws_h, ws_f, ws_g [S*n, D]; ws_mod [S*n, (3*depth+2)*D]. */
+int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const float* dt,
+                         const float* guidance, int steps, int S, int B, int n, int P, int D, void* ws_a, void* ws_u,
+                         void* ws_h, void* ws_f, void* ws_g, void* ws_mod, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOVA_HIP_H_ */

@@ -1,0 +1,316 @@
+// NOVA hot path: non-causal multi-head self-attention over [prefix ; point tokens]
+//   o = softmax(q k^T * scale) v        (reference diffnext/models/vision_transformer.py:63,
+//   F.scaled_dot_product_attention with attn_mask=None; L <= Nv + N = 2560 at 2048 points)
+//
+// q/k/v are read IN PLACE from the fused-QKV GEMM output [S*L, 3D] (row strides passed in), so the
+// reference's view/permute/unbind (vision_transformer.py:52-53) never materialises; o is written
+// merged-head [S*L, D], which is what the out-projection GEMM consumes (vision_transformer.py:64).
+//
+// bf16 kernel (throughput mode): flash-style, one 256-thread workgroup = 128 query rows of one
+// (sequence, head); each wave owns 32 query rows with Q resident in registers. K/V tiles of 64
+// keys stream global->LDS by 16-byte LDS-DMA, double buffered, one barrier per tile.
+//   S^T = K Q^T  with v_mfma_f32_32x32x16_bf16 (K fragment = A operand): every lane then holds
+//   one query COLUMN, so the online-softmax max/sum are lane-local plus one xor-32 shuffle.
+//   O^T = V^T P^T: the S^T accumulator, converted pairwise to bf16, IS the B operand of the next
+//   MFMA (no LDS round trip); V^T fragments come from the row-major V tile through the hardware
+//   transposing read ds_read_b64_tr_b16. Rescale factors and 1/l are lane-local as well.
+// f32 kernel (parity mode): same skeleton on v_mfma_f32_32x32x2_f32 (exact f32), 32-key tiles.
+#include "common.h"
+#include "nova_internal.h"
+
+namespace nova {
+
+constexpr float NEG_INF = -__builtin_huge_valf();
+
+// ------------------------------------------------------------------------------------------
+// bf16, head_dim 64
+// ------------------------------------------------------------------------------------------
+constexpr int A_KV = 64;             // keys per tile
+constexpr int A_ROWB = 128;          // bytes per K/V row (64 x bf16)
+constexpr int A_TILE = A_KV * A_ROWB;  // 8 KiB
+
+__global__ __launch_bounds__(256) void attn_bf16_hd64(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                      const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int Lq,
+                                                      int Lk, long q_rs, long kv_rs, long o_rs, float c) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * A_TILE];  // [buf][K|V]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, s = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+
+  const bf16_t* qb = q + (size_t)s * Lq * q_rs + head * 64;
+  const bf16_t* kb_ = k + (size_t)s * Lk * kv_rs + head * 64;
+  const bf16_t* vb_ = v + (size_t)s * Lk * kv_rs + head * 64;
+
+  // Q fragments: B operand of S^T = K Q^T; lane (r, hh) holds Q[q0 + r][16 ks + 8 hh + 0..7]
+  bf8v qf[4];
+  {
+    const int qrow = min(q0 + r, Lq - 1);
+    const bf16_t* qp = qb + (size_t)qrow * q_rs + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf8v*>(qp + 16 * ks);
+  }
+
+  // staging: wave w moves LDS-DMA pieces 2w, 2w+1 (8 rows x 128 B) of the K tile and of the V tile
+  const int rr = lane >> 3, cp = lane & 7;
+  auto stage = [&](int buf, int kt) {
+    char* lk = smem + buf * 2 * A_TILE;
+    char* lv = lk + A_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wid * 2 + i, row = piece * 8 + rr;
+      const int key = min(kt * A_KV + row, Lk - 1);
+      const int ck = cp ^ ((row >> 1) & 7);           // K image: conflict-free ds_read_b128 by row
+      const int cv = cp ^ (((row >> 1) & 1) << 2);    // V image: conflict-free ds_read_b64_tr_b16
+      __builtin_amdgcn_global_load_lds(kb_ + (size_t)key * kv_rs + ck * 8, NOVA_LDS_PTR(lk + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vb_ + (size_t)key * kv_rs + cv * 8, NOVA_LDS_PTR(lv + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f16v ot[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+
+  // per-lane constants of the transposing V read: lane 4*qr + p of each 16-lane group supplies
+  // the address of row key0 + qr, columns dv0 + 4p .. 4p+3
+  const int t_qr = (lane & 15) >> 2, t_p = lane & 3, t_gp = (lane >> 4) & 1;
+
+  const int nkt = (Lk + A_KV - 1) / A_KV;
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    const char* tk = smem + (kt & 1) * 2 * A_TILE;
+    const char* tv = tk + A_TILE;
+
+    // ---- S^T[key][q] for the two 32-key blocks
+    f16v st[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
+      const int row = kb * 32 + r;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int phys = (2 * ks + hh) ^ ((row >> 1) & 7);
+        const bf8v kf = *reinterpret_cast<const bf8v*>(tk + row * A_ROWB + phys * 16);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+      }
+    }
+    if (kt == nkt - 1 && (Lk & (A_KV - 1)) != 0) {  // ragged last tile: keys >= Lk contribute nothing
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int key = kt * A_KV + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (key >= Lk) st[kb][i] = NEG_INF;
+        }
+    }
+
+    // ---- online softmax, lane-local per query column (partner lane^32 holds the other keys)
+    float mx = st[0][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    m_run = m_new;
+    float psum = 0.f;
+    bf8v pb[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(st[kb][8 * s2 + j] * c - mc);
+          psum += p;
+          pb[kb][s2][j] = (__bf16)p;
+        }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+
+    // ---- O^T[dv][q] += V^T[dv][key] P^T[key][q]
+#pragma unroll
+    for (int dvb = 0; dvb < 2; ++dvb) {
+      const int col = dvb * 32 + 16 * t_gp + 4 * t_p;
+      const int chunk = col >> 3, within = (t_p & 1) * 8;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int row0 = kb * 32 + 16 * s2 + 4 * hh + t_qr;
+          const int row1 = row0 + 8;
+          const char* a0 = tv + row0 * A_ROWB + ((chunk ^ (((row0 >> 1) & 1) << 2)) * 16) + within;
+          const char* a1 = tv + row1 * A_ROWB + ((chunk ^ (((row1 >> 1) & 1) << 2)) * 16) + within;
+          const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
+          const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a1);
+          const bf8v vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          ot[dvb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][s2], ot[dvb], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- finalize: lane (r, hh) holds O[q0 + r][dvb*32 + (i&3) + 8(i>>2) + 4hh]
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + r;
+  if (qrow < Lq) {
+    bf16_t* op = o + ((size_t)s * Lq + qrow) * o_rs + head * 64;
+#pragma unroll
+    for (int dvb = 0; dvb < 2; ++dvb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = dvb * 32 + 8 * g + 4 * hh;
+        u2v pk = {pack_bf2(ot[dvb][4 * g] * inv, ot[dvb][4 * g + 1] * inv),
+                  pack_bf2(ot[dvb][4 * g + 2] * inv, ot[dvb][4 * g + 3] * inv)};
+        *reinterpret_cast<u2v*>(op + dv) = pk;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 (parity mode), head_dim 64, 32-key tiles, exact-f32 MFMA
+// ------------------------------------------------------------------------------------------
+constexpr int F_KV = 32;
+constexpr int F_ROWB = 256;            // 64 x f32
+constexpr int F_TILE = F_KV * F_ROWB;  // 8 KiB
+
+__global__ __launch_bounds__(256) void attn_f32_hd64(const float* __restrict__ q, const float* __restrict__ k,
+                                                     const float* __restrict__ v, float* __restrict__ o, int Lq,
+                                                     int Lk, long q_rs, long kv_rs, long o_rs, float c) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * F_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int head = blockIdx.y, s = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+
+  const float* qb = q + (size_t)s * Lq * q_rs + head * 64;
+  const float* kb_ = k + (size_t)s * Lk * kv_rs + head * 64;
+  const float* vb_ = v + (size_t)s * Lk * kv_rs + head * 64;
+
+  // lane (r, hh) holds Q[q0 + r][4 (2 cs + hh) + j]; MFMA step (cs, j) contracts the k pair
+  // {4(2cs)+j, 4(2cs+1)+j} (any consistent order is a valid contraction)
+  f4v qf[8];
+  {
+    const int qrow = min(q0 + r, Lq - 1);
+    const float* qp = qb + (size_t)qrow * q_rs + 4 * hh;
+#pragma unroll
+    for (int cs = 0; cs < 8; ++cs) qf[cs] = *reinterpret_cast<const f4v*>(qp + 8 * cs);
+  }
+
+  const int rr = lane >> 4, cp = lane & 15;
+  auto stage = [&](int buf, int kt) {
+    char* lk = smem + buf * 2 * F_TILE;
+    char* lv = lk + F_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int piece = wid * 2 + i, row = piece * 4 + rr;
+      const int key = min(kt * F_KV + row, Lk - 1);
+      const int ck = cp ^ (row & 15);
+      __builtin_amdgcn_global_load_lds(kb_ + (size_t)key * kv_rs + ck * 4, NOVA_LDS_PTR(lk + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vb_ + (size_t)key * kv_rs + cp * 4, NOVA_LDS_PTR(lv + piece * 1024), 16, 0, 0);
+    }
+  };
+
+  f16v ot[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
+  float m_run = NEG_INF, l_run = 0.f;
+
+  const int nkt = (Lk + F_KV - 1) / F_KV;
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    const char* tk = smem + (kt & 1) * 2 * F_TILE;
+    const float* tv = reinterpret_cast<const float*>(tk + F_TILE);
+
+    f16v st;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[i] = 0.f;
+#pragma unroll
+    for (int cs = 0; cs < 8; ++cs) {
+      const int phys = (2 * cs + hh) ^ (r & 15);
+      const f4v kf = *reinterpret_cast<const f4v*>(tk + r * F_ROWB + phys * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[cs][j], st, 0, 0, 0);
+    }
+    if (kt == nkt - 1 && (Lk & (F_KV - 1)) != 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kt * F_KV + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (key >= Lk) st[i] = NEG_INF;
+      }
+    }
+
+    float mx = st[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      st[i] = exp2f(st[i] * c - mc);
+      psum += st[i];
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+
+#pragma unroll
+    for (int dvb = 0; dvb < 2; ++dvb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const float vv = tv[key * 64 + dvb * 32 + r];
+        ot[dvb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[i], ot[dvb], 0, 0, 0);
+      }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + r;
+  if (qrow < Lq) {
+    float* op = o + ((size_t)s * Lq + qrow) * o_rs + head * 64;
+#pragma unroll
+    for (int dvb = 0; dvb < 2; ++dvb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dv = dvb * 32 + 8 * g + 4 * hh;
+        f4v ov = {ot[dvb][4 * g] * inv, ot[dvb][4 * g + 1] * inv, ot[dvb][4 * g + 2] * inv, ot[dvb][4 * g + 3] * inv};
+        *reinterpret_cast<f4v*>(op + dv) = ov;
+      }
+  }
+}
+
+int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
+             long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st) {
+  if (S <= 0 || Lq <= 0) return 0;
+  if (hd != 64) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64)", hd);
+  if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
+  const int align = dtype == NOVA_BF16 ? 8 : 4;  // 16-byte row alignment for the vector loads
+  if (q_rs % align || kv_rs % align || o_rs % align) return set_error(NOVA_ERR_SHAPE, "attn_fwd: row strides must be 16-byte multiples");
+  if (S > 65535 || heads > 65535) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
+  const float c = scale * 1.4426950408889634f;
+  dim3 grid((Lq + 127) / 128, heads, S), block(256);
+  if (dtype == NOVA_BF16) {
+    hipLaunchKernelGGL(attn_bf16_hd64, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);
+  } else {
+    hipLaunchKernelGGL(attn_f32_hd64, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v,
+                       (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);
+  }
+  return check_launch("attn_fwd");
+}
+
+}  // namespace nova

@@ -1,0 +1,209 @@
+// C ABI of libnova_hip.so (declared in include/nova_hip.h): argument checks, error record,
+// and the composite launch sequences (ViT block stack, diffusion-MLP denoise loop).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include "common.h"
+#include "nova_internal.h"
+
+namespace nova {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return 0;
+  return set_error(NOVA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+static inline bool bad_dtype(int dtype) { return dtype != NOVA_F32 && dtype != NOVA_BF16; }
+static inline size_t esize(int dtype) { return dtype == NOVA_BF16 ? 2 : 4; }
+
+}  // namespace nova
+
+using namespace nova;
+
+#define NOVA_REQUIRE(cond, code, ...) \
+  do {                                \
+    if (!(cond)) return set_error(code, __VA_ARGS__); \
+  } while (0)
+#define NOVA_TRY(expr)        \
+  do {                        \
+    const int rc_ = (expr);   \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+extern "C" {
+
+int nova_version(void) { return NOVA_HIP_VERSION; }
+const char* nova_last_error(void) { return g_err; }
+
+int nova_check_device(void) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return set_error(NOVA_ERR_DEVICE, "no HIP device");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return set_error(NOVA_ERR_DEVICE, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(NOVA_ERR_DEVICE, "device %d is %s; libnova_hip is built for gfx950 only", dev, prop.gcnArchName);
+  return 0;
+}
+
+int nova_gemm_bias_act(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
+                       int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "gemm: bad dtype %d", dtype);
+  NOVA_REQUIRE(M == 0 || (A && W && out), NOVA_ERR_ARG, "gemm: null pointer");
+  return gemm_bias_act(A, W, bias, out, M, N, K, act, dtype, (hipStream_t)stream);
+}
+
+int nova_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L, int D,
+                  int heads, int rope_batch, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "qkv_rope: bad dtype %d", dtype);
+  NOVA_REQUIRE(S * L == 0 || (x && Wqkv && qkv), NOVA_ERR_ARG, "qkv_rope: null pointer");
+  return gemm_qkv_rope(x, Wqkv, bias, rope, qkv, S, L, D, heads, rope_batch, dtype, (hipStream_t)stream);
+}
+
+int nova_rope_table(const float* pos, const long long* ids, float* rope, int nb, int pad, int n_tok, int n_pos, int hd,
+                    const float* inv_freq, void* stream) {
+  NOVA_REQUIRE(pos && rope && inv_freq, NOVA_ERR_ARG, "rope_table: null pointer");
+  NOVA_REQUIRE(hd > 0 && hd % 8 == 0, NOVA_ERR_SHAPE, "rope_table: head_dim %d", hd);
+  return rope_table(pos, ids, rope, nb, pad, n_tok, n_pos, hd, inv_freq, (hipStream_t)stream);
+}
+
+int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int head_dim,
+                  long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "attn_fwd: bad dtype %d", dtype);
+  NOVA_REQUIRE(q && k && v && o, NOVA_ERR_ARG, "attn_fwd: null pointer");
+  return attn_fwd(q, k, v, o, S, heads, Lq, Lk, head_dim, q_row_stride, kv_row_stride, o_row_stride, scale, dtype,
+                  (hipStream_t)stream);
+}
+
+int nova_row_norm(const void* in, void* out, const float* gamma, const float* beta, const void* mod, long mod_ld,
+                  int scale_off, int shift_off, int gate_off, const void* res, const int* gather, long rows, int D,
+                  float eps, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "row_norm: bad dtype %d", dtype);
+  NOVA_REQUIRE(rows == 0 || (in && out), NOVA_ERR_ARG, "row_norm: null pointer");
+  RowNormArgs a{in, out, gamma, beta, mod, mod_ld, scale_off, shift_off, gate_off, res, gather, rows, D, eps};
+  return row_norm(a, dtype, (hipStream_t)stream);
+}
+
+int nova_embed_canvas(const float* canvas, const float* mask, const void* w, const float* bias, const void* mask_token,
+                      const void* pos_embed, void* z0, int B, int N, int P, int D, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "embed_canvas: bad dtype %d", dtype);
+  NOVA_REQUIRE(canvas && mask && w && bias && mask_token && z0, NOVA_ERR_ARG, "embed_canvas: null pointer");
+  return embed_canvas(canvas, mask, w, bias, mask_token, pos_embed, z0, B, N, P, D, dtype, (hipStream_t)stream);
+}
+
+int nova_build_sequence(const void* prefix, long prefix_seq_rows, const void* tokens, long tok_batch_rows,
+                        const long long* ids, void* x, int S, int B, int Lp, int n_sel, int D, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "build_sequence: bad dtype %d", dtype);
+  NOVA_REQUIRE(x && (Lp == 0 || prefix) && (n_sel == 0 || tokens) && B > 0, NOVA_ERR_ARG, "build_sequence: null pointer");
+  return build_sequence(prefix, prefix_seq_rows, tokens, tok_batch_rows, ids, x, S, B, Lp, n_sel, D, dtype, (hipStream_t)stream);
+}
+
+int nova_scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B, int Lp, int N, int n_prev, int D,
+                        int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "scatter_tokens: bad dtype %d", dtype);
+  NOVA_REQUIRE(n_prev == 0 || (x1 && ids && x2 && B > 0), NOVA_ERR_ARG, "scatter_tokens: null pointer");
+  return scatter_tokens(x1, ids, x2, S, B, Lp, N, n_prev, D, dtype, (hipStream_t)stream);
+}
+
+int nova_silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "silu_add_rows: bad dtype %d", dtype);
+  NOVA_REQUIRE(rows == 0 || (a && out), NOVA_ERR_ARG, "silu_add_rows: null pointer");
+  return silu_add_rows(a, rowvec, out, rows, D, dtype, (hipStream_t)stream);
+}
+
+int nova_timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "timestep_freq: bad dtype %d", dtype);
+  NOVA_REQUIRE(t && freq && out && freq_dim % 2 == 0, NOVA_ERR_ARG, "timestep_freq: bad argument");
+  return timestep_freq(t, freq, out, n, freq_dim, dtype, (hipStream_t)stream);
+}
+
+int nova_patch_embed_rows(const float* x, const void* w, const float* bias, void* out, int S, int B, int n, int P, int D,
+                          int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "patch_embed_rows: bad dtype %d", dtype);
+  NOVA_REQUIRE(x && w && bias && out && B > 0, NOVA_ERR_ARG, "patch_embed_rows: null pointer");
+  return patch_embed_rows(x, w, bias, out, S, B, n, P, D, dtype, (hipStream_t)stream);
+}
+
+int nova_head_cfg_euler(const void* h, const void* w, const float* bias, float* x, int B, int n, int P, int D,
+                        float guidance, int cfg, float dt, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "head_cfg_euler: bad dtype %d", dtype);
+  NOVA_REQUIRE(h && w && bias && x, NOVA_ERR_ARG, "head_cfg_euler: null pointer");
+  return head_cfg_euler(h, w, bias, x, B, n, P, D, guidance, cfg, dt, dtype, (hipStream_t)stream);
+}
+
+int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
+                            int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
+                            void* ws_h, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "vit_blocks: bad dtype %d", dtype);
+  NOVA_REQUIRE(nblocks == 0 || (blocks && x && ws_qkv && ws_a && ws_b && ws_h), NOVA_ERR_ARG, "vit_blocks: null pointer");
+  NOVA_REQUIRE(heads > 0 && D % heads == 0, NOVA_ERR_SHAPE, "vit_blocks: D %% heads != 0");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = S * L, hd = D / heads;
+  if (M == 0) return 0;
+  const size_t es = esize(dtype);
+  const float scale = 1.0f / sqrtf((float)hd);
+  const char* qkv = static_cast<const char*>(ws_qkv);
+  for (int i = 0; i < nblocks; ++i) {
+    const nova_vit_block& b = blocks[i];
+    NOVA_TRY(gemm_qkv_rope(x, b.qkv_w, b.qkv_b, rope, ws_qkv, S, L, D, heads, rope_batch, dtype, st));
+    NOVA_TRY(attn_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, ws_a, S, heads, L, L, hd, 3L * D, 3L * D, D,
+                      scale, dtype, st));
+    NOVA_TRY(gemm_bias_act(ws_a, b.proj_w, b.proj_b, ws_b, M, D, D, NOVA_ACT_NONE, dtype, st));
+    RowNormArgs n1{ws_b, x, b.norm1_w, b.norm1_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
+    NOVA_TRY(row_norm(n1, dtype, st));
+    NOVA_TRY(gemm_bias_act(x, b.fc1_w, b.fc1_b, ws_h, M, hidden, D, NOVA_ACT_GELU_ERF, dtype, st));
+    NOVA_TRY(gemm_bias_act(ws_h, b.fc2_w, b.fc2_b, ws_b, M, D, hidden, NOVA_ACT_NONE, dtype, st));
+    RowNormArgs n2{ws_b, x, b.norm2_w, b.norm2_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
+    NOVA_TRY(row_norm(n2, dtype, st));
+  }
+  return 0;
+}
+
+int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const float* dt,
+                         const float* guidance, int steps, int S, int B, int n, int P, int D, void* ws_a, void* ws_u,
+                         void* ws_h, void* ws_f, void* ws_g, void* ws_mod, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "decoder_denoise: bad dtype %d", dtype);
+  NOVA_REQUIRE(dec && zc && temb && x && dt && guidance && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
+               "decoder_denoise: null pointer");
+  NOVA_REQUIRE(S == B || S == 2 * B, NOVA_ERR_SHAPE, "decoder_denoise: S must be B or 2B");
+  if (n == 0 || B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t es = esize(dtype);
+  const int depth = dec->depth;
+  const long mod_ld = (long)(3 * depth + 2) * D;
+  for (int i = 0; i < steps; ++i) {
+    const int cfg = guidance[i] > 1.0f ? 1 : 0;
+    NOVA_REQUIRE(!cfg || S == 2 * B, NOVA_ERR_SHAPE, "decoder_denoise: guidance > 1 needs S = 2B");
+    const int Se = cfg ? 2 * B : B;
+    const long rows = (long)Se * n;
+    NOVA_TRY(silu_add_rows(zc, static_cast<const char*>(temb) + (size_t)i * D * es, ws_a, rows, D, dtype, st));
+    NOVA_TRY(gemm_bias_act(ws_a, dec->adaln_w, dec->adaln_b, ws_mod, (int)rows, (int)mod_ld, D, NOVA_ACT_NONE, dtype, st));
+    NOVA_TRY(patch_embed_rows(x, dec->patch_w, dec->patch_b, ws_u, Se, B, n, P, D, dtype, st));
+    for (int b = 0; b < depth; ++b) {
+      const nova_mlp_block& blk = dec->blocks[b];
+      RowNormArgs m1{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, b * 3 * D, b * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
+      NOVA_TRY(row_norm(m1, dtype, st));
+      NOVA_TRY(gemm_bias_act(ws_h, blk.fc1_w, blk.fc1_b, ws_f, (int)rows, D, D, NOVA_ACT_SILU, dtype, st));
+      NOVA_TRY(gemm_bias_act(ws_f, blk.fc2_w, blk.fc2_b, ws_g, (int)rows, D, D, NOVA_ACT_NONE, dtype, st));
+      RowNormArgs m2{ws_g, ws_u, blk.norm2_w, blk.norm2_b, ws_mod, mod_ld, -1, -1, b * 3 * D + 2 * D, ws_u, nullptr, rows, D, 1e-5f};
+      NOVA_TRY(row_norm(m2, dtype, st));
+    }
+    RowNormArgs mf{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, depth * 3 * D, depth * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
+    NOVA_TRY(row_norm(mf, dtype, st));
+    NOVA_TRY(head_cfg_euler(ws_h, dec->head_w, dec->head_b, x, B, n, P, D, guidance[i], cfg, dt[i], dtype, st));
+  }
+  return 0;
+}
+
+}  // extern "C"

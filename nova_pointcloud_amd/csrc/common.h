@@ -1,0 +1,58 @@
+// Shared device helpers for the NOVA gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nova {
+
+typedef __attribute__((ext_vector_type(8))) short s8v;   // 8 x bf16 bit patterns (one MFMA A/B fragment)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8v;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf4v;
+typedef __attribute__((ext_vector_type(4))) short s4v;
+typedef __attribute__((ext_vector_type(4))) float f4v;
+typedef __attribute__((ext_vector_type(16))) float f16v;
+typedef __attribute__((ext_vector_type(4))) uint32_t u4v;
+typedef __attribute__((ext_vector_type(2))) uint32_t u2v;
+
+typedef uint16_t bf16_t;  // storage type for bf16 tensors
+
+#define NOVA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even via the hardware cvt (keeps NaN a NaN, MI355X_MICROARCH correctness table)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a
+// contiguous chunk of the logical tile list, so neighbouring tiles hit the same per-XCD L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+}  // namespace nova

@@ -1,0 +1,219 @@
+// NOVA hot path: dense projection GEMM  out[M,N] = epi(A[M,K] · W[N,K]^T + bias[N])
+//
+// Replaces, on the device, every nn.Linear of the reference's ViT blocks and diffusion MLP
+// (reference diffnext/models/vision_transformer.py:33-38,47-48,52,64; diffusion_mlp.py:31-36;
+// normalization.py:28,35). Weights keep the reference's nn.Linear layout [N][K] (K contiguous),
+// so both MFMA operands are K-contiguous and no transpose is ever materialised.
+//
+// Structure (MI355X-first, not a port): 128x128 output tile per 256-thread workgroup (4 waves as
+// 2x2, 64x64 per wave = 4x4 MFMA 16x16 fragments), K-tile of 128 BYTES per row (64 bf16 / 32 f32),
+// both operand tiles streamed global->LDS with 16-byte LDS-DMA (global_load_lds_dwordx4), double
+// buffered, one barrier per K-tile. The LDS image is lane-linear (DMA requirement), so the
+// bank-conflict XOR swizzle is applied to the per-lane SOURCE address and to the ds_read_b128
+// address (cdna_hip_programming.md rule 21). The MFMA is issued with the WEIGHT fragment as the
+// A operand so each lane ends up holding 4 consecutive output columns of one row: bias / GELU /
+// SiLU / RoPE pairs are lane-local and the store is 8 B (bf16) or 16 B (f32) per lane.
+// bf16: v_mfma_f32_16x16x32_bf16; f32 (parity mode): v_mfma_f32_16x16x4_f32 (exact f32).
+#include "common.h"
+#include "nova_internal.h"
+
+namespace nova {
+
+constexpr int BM = 128, BN = 128, ROWB = 128;       // ROWB: bytes of K per tile row
+constexpr int TILE_BYTES = BM * ROWB;               // 16 KiB per operand tile
+constexpr int GEMM_LDS = 4 * TILE_BYTES;            // A,W x 2 buffers = 64 KiB
+
+struct GemmEpi {
+  const float* bias;     // [N] or nullptr
+  const float* rope;     // [rope_batch, L, hd/2, 2] (cos, sin) or nullptr
+  int L;                 // tokens per sequence (rows m -> (s = m / L, l = m % L))
+  int rope_batch;        // table batch count; sequence s uses table s % rope_batch
+  int hd;                // head dim
+  int rope_cols;         // columns [0, rope_cols) are rotated (q and k thirds of the fused QKV)
+};
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU = 2, EPI_ROPE = 3 };
+
+template <typename T> struct Frag;   // one 16-byte LDS read = the per-lane K slice of a fragment
+template <> struct Frag<bf16_t> { bf8v v; };
+template <> struct Frag<float> { f4v v; };
+
+__device__ __forceinline__ f4v mma(const Frag<bf16_t>& w, const Frag<bf16_t>& a, f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f4v mma(const Frag<float>& w, const Frag<float>& a, f4v c) {
+  // 4 exact-f32 MFMAs; lane group g = lane>>4 supplies k-slot g of each, so the logical k of
+  // (chunk, j) is 4*chunk + j on BOTH operands (any consistent k order is a valid contraction).
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[j], a.v[j], c, 0, 0, 0);
+  return c;
+}
+
+template <typename T>
+__device__ __forceinline__ Frag<T> lds_frag(const char* tile, int row, int chunk) {
+  const int phys = chunk ^ ((row >> 1) & 7);
+  Frag<T> f;
+  f.v = *reinterpret_cast<const decltype(f.v)*>(tile + row * ROWB + phys * 16);
+  return f;
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                       T* __restrict__ C, int M, int N, int K, int ntm,
+                                                       int ntn, GemmEpi e) {
+  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // XCD-aware + grouped tile order: 8 row panels x all column panels per group, row fastest.
+  const int nwg = ntm * ntn;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  constexpr int GM = 8;
+  const int per_group = GM * ntn;
+  const int group = t / per_group, first_m = group * GM;
+  const int gsz = min(ntm - first_m, GM);
+  const int tm = first_m + (t % per_group) % gsz;
+  const int tn = (t % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- staging addresses: wave w owns LDS-DMA pieces 4w..4w+3 (8 rows x 128 B each) of A and W
+  const int rr = lane >> 3, cp = lane & 7;
+  const char* a_src[4];
+  const char* w_src[4];
+  const size_t rowbytes = (size_t)K * sizeof(T);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wid * 4 + i) * 8 + rr;                 // row inside the tile
+    const int c = cp ^ ((row >> 1) & 7);                    // logical 16-B chunk this lane fetches
+    const int am = min(m0 + row, M - 1);                    // clamp: rows past M are never stored
+    a_src[i] = reinterpret_cast<const char*>(A) + (size_t)am * rowbytes + c * 16;
+    w_src[i] = reinterpret_cast<const char*>(W) + (size_t)(n0 + row) * rowbytes + c * 16;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* la = smem + buf * 2 * TILE_BYTES + wid * 4096;
+    char* lw = la + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(a_src[i] + (size_t)kt * ROWB, NOVA_LDS_PTR(la + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(w_src[i] + (size_t)kt * ROWB, NOVA_LDS_PTR(lw + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f4v acc[4][4];  // [nf][mf]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = K / (ROWB / (int)sizeof(T));
+  const int fr = lane & 15, fg = lane >> 4;
+
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // tile kt landed (compiler drains vmcnt before the barrier); buffer (kt+1)&1 free
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    const char* ta = smem + (kt & 1) * 2 * TILE_BYTES;
+    const char* tw = ta + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      Frag<T> af[4], wf[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        af[f] = lds_frag<T>(ta, wm * 64 + f * 16 + fr, fg + 4 * kk);
+        wf[f] = lds_frag<T>(tw, wn * 64 + f * 16 + fr, fg + 4 * kk);
+      }
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mma(wf[nf], af[mf], acc[nf][mf]);
+    }
+  }
+
+  // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4)
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    const int m = m0 + wm * 64 + mf * 16 + fr;
+    if (m >= M) continue;
+    const float* ropem = nullptr;
+    if (EPI == EPI_ROPE) {
+      const int s = m / e.L, l = m - s * e.L;
+      ropem = e.rope + ((size_t)(s % e.rope_batch) * e.L + l) * e.hd;  // hd/2 pairs x (cos, sin)
+    }
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      const int n = n0 + wn * 64 + nf * 16 + fg * 4;
+      f4v v = acc[nf][mf];
+      if (e.bias) {
+        const f4v b = *reinterpret_cast<const f4v*>(e.bias + n);
+        v += b;
+      }
+      if (EPI == EPI_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+      } else if (EPI == EPI_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
+      } else if (EPI == EPI_ROPE) {
+        if (n < e.rope_cols) {
+          const int dd = n % e.hd;  // multiple of 4: pairs (dd, dd+1), (dd+2, dd+3)
+          const f4v cs = *reinterpret_cast<const f4v*>(ropem + dd);  // cos0, sin0, cos1, sin1
+          const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+          v[0] = cs[0] * x0 - cs[1] * x1;
+          v[1] = cs[1] * x0 + cs[0] * x1;
+          v[2] = cs[2] * x2 - cs[3] * x3;
+          v[3] = cs[3] * x2 + cs[2] * x3;
+        }
+      }
+      T* dst = C + (size_t)m * N + n;
+      if constexpr (sizeof(T) == 2) {
+        u2v o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u2v*>(dst) = o;
+      } else {
+        *reinterpret_cast<f4v*>(dst) = v;
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi& e,
+                       hipStream_t st) {
+  const int kelems = ROWB / (int)sizeof(T);
+  if (M <= 0) return 0;
+  if (N % BN != 0 || K % kelems != 0 || K <= 0)
+    return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
+  const int ntm = (M + BM - 1) / BM, ntn = N / BN;
+  dim3 grid(ntm * ntn), block(256);
+  const T* a = static_cast<const T*>(A);
+  const T* w = static_cast<const T*>(W);
+  T* c = static_cast<T*>(C);
+  switch (epi) {
+    case EPI_NONE: hipLaunchKernelGGL((gemm_kernel<T, EPI_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case EPI_GELU: hipLaunchKernelGGL((gemm_kernel<T, EPI_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case EPI_SILU: hipLaunchKernelGGL((gemm_kernel<T, EPI_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case EPI_ROPE: hipLaunchKernelGGL((gemm_kernel<T, EPI_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    default: return set_error(NOVA_ERR_ARG, "gemm: unknown epilogue %d", epi);
+  }
+  return check_launch("gemm");
+}
+
+int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
+                  int dtype, hipStream_t st) {
+  GemmEpi e{bias, nullptr, 1, 1, 2, 0};
+  if (act < 0 || act > 2) return set_error(NOVA_ERR_ARG, "gemm: unknown activation %d", act);
+  return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(A, W, out, M, N, K, act, e, st)
+                            : launch_gemm<float>(A, W, out, M, N, K, act, e, st);
+}
+
+int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L,
+                  int D, int heads, int rope_batch, int dtype, hipStream_t st) {
+  const int hd = D / heads;
+  if (heads <= 0 || D % heads != 0 || hd % 4 != 0) return set_error(NOVA_ERR_SHAPE, "qkv_rope: bad heads/D");
+  const int epi = rope ? EPI_ROPE : EPI_NONE;
+  if (rope && rope_batch <= 0) return set_error(NOVA_ERR_ARG, "qkv_rope: rope_batch must be > 0");
+  GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, 2 * D};
+  return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st)
+                            : launch_gemm<float>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st);
+}
+
+}  // namespace nova

@@ -1,0 +1,55 @@
+// Internal declarations shared by the kernel translation units and the C ABI (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/nova_hip.h"
+
+namespace nova {
+
+// thread-local last-error record; returns `code` so callers can `return set_error(...)`.
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// hipGetLastError() -> NOVA_ERR_LAUNCH (+ message) or 0. Never synchronises.
+int check_launch(const char* what);
+
+// ---- gemm.hip
+int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
+                  int dtype, hipStream_t st);
+int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L,
+                  int D, int heads, int rope_batch, int dtype, hipStream_t st);
+
+// ---- attn.hip
+int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
+             long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st);
+
+// ---- rowops.hip
+struct RowNormArgs {
+  const void* in;        // [rows, D]
+  void* out;             // [rows, D]
+  const float* gamma;    // [D] or null
+  const float* beta;     // [D] or null
+  const void* mod;       // modulation rows [rows, mod_ld] or null
+  long mod_ld;
+  int scale_off, shift_off, gate_off;   // column offsets inside a mod row; -1 = absent
+  const void* res;       // residual [rows, D] or null
+  const int* gather;     // optional source row index per output row (rows of `in`), or null
+  long rows;
+  int D;
+  float eps;
+};
+int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
+
+int rope_table(const float* pos, const long long* ids, float* table, int nb, int pad, int n_tok, int n_pos,
+               int hd, const float* inv_freq, hipStream_t st);
+int embed_canvas(const float* canvas, const float* mask, const void* w, const float* bias, const void* mask_token,
+                 const void* pos_embed, void* z0, int B, int N, int P, int D, int dtype, hipStream_t st);
+int build_sequence(const void* prefix, long prefix_seq_rows, const void* tokens, long tok_batch_rows,
+                   const long long* ids, void* x, int S, int B, int Lp, int n_sel, int D, int dtype, hipStream_t st);
+int scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B, int Lp, int N, int n_prev, int D,
+                   int dtype, hipStream_t st);
+int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, hipStream_t st);
+int timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, hipStream_t st);
+int patch_embed_rows(const float* x, const void* w, const float* bias, void* out, int S, int B, int n, int P, int D,
+                     int dtype, hipStream_t st);
+int head_cfg_euler(const void* h, const void* w, const float* bias, float* x, int B, int n, int P, int D,
+                   float guidance, int cfg, float dt, int dtype, hipStream_t st);
+
+}  // namespace nova

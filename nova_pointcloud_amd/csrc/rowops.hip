@@ -1,0 +1,382 @@
+// NOVA hot path: row-wise (HBM-bound) kernels between the GEMMs and around the AR loop.
+// One wave (64 lanes) owns one row; reductions are wave shuffles; all loads/stores are 16-byte
+// (f32) or 8-byte (bf16) vectors; statistics and arithmetic are always f32.
+//
+//   row_norm         LayerNorm family: post-norm residual of the ViT block
+//                    (reference vision_transformer.py:78-82,91-92), AdaLN-Zero modulate
+//                    (normalization.py:34-36), gate*LN+residual of the diffusion block
+//                    (diffusion_mlp.py:52-53), final encoder LN with row gather
+//                    (vision_transformer.py:146 + diffusion_mlp.py:93)
+//   rope_table       cos/sin table of RotaryEmbed3D.get_func (embeddings.py:59-67)
+//   embed_canvas     PatchEmbed conv (k = s = p) + MaskEmbed blend (+ abs-PE)
+//                    (embeddings.py:160-166, 272-274, 90-91)
+//   build_sequence   cat([c ; gather(x, prev_ids)]) (vision_transformer.py:133-136)
+//   scatter_tokens   x_masked.scatter(1, prev_ids, x) (vision_transformer.py:141-143)
+//   silu_add_rows, timestep_freq, patch_embed_rows, head_cfg_euler: diffusion-MLP glue
+//                    (diffusion_mlp.py:65-75,89-99; guidance_scaler.py:86-87; scheduling_cfm.py:134-136)
+#include "common.h"
+#include "nova_internal.h"
+
+namespace nova {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ f4v load(const float* p) { return *reinterpret_cast<const f4v*>(p); }
+  static __device__ __forceinline__ void store(float* p, f4v v) { *reinterpret_cast<f4v*>(p) = v; }
+};
+template <> struct Vec4<bf16_t> {
+  static __device__ __forceinline__ f4v load(const bf16_t* p) {
+    const u2v u = *reinterpret_cast<const u2v*>(p);
+    return f4v{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16),
+               __uint_as_float(u[1] & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, f4v v) {
+    u2v u = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    *reinterpret_cast<u2v*>(p) = u;
+  }
+};
+
+constexpr int RN_MAXIT = 8;  // 8 x 256 = up to D = 2048 per row held in registers
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const long src = a.gather ? (long)a.gather[row] : row;
+  const T* in = static_cast<const T*>(a.in) + src * a.D;
+  f4v x[RN_MAXIT];
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < RN_MAXIT; ++it) {
+    const int d = (it * 64 + lane) * 4;
+    if (d < a.D) {
+      x[it] = Vec4<T>::load(in + d);
+      sum += (x[it][0] + x[it][1]) + (x[it][2] + x[it][3]);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)a.D;
+  float sq = 0.f;
+#pragma unroll
+  for (int it = 0; it < RN_MAXIT; ++it) {
+    const int d = (it * 64 + lane) * 4;
+    if (d < a.D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float c = x[it][j] - mean;
+        sq += c * c;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)a.D + a.eps);
+  const T* mod = a.mod ? static_cast<const T*>(a.mod) + row * a.mod_ld : nullptr;
+  const T* res = a.res ? static_cast<const T*>(a.res) + row * a.D : nullptr;
+  T* out = static_cast<T*>(a.out) + row * a.D;
+#pragma unroll
+  for (int it = 0; it < RN_MAXIT; ++it) {
+    const int d = (it * 64 + lane) * 4;
+    if (d < a.D) {
+      f4v y = (x[it] - mean) * rstd;
+      if (a.gamma) y = y * *reinterpret_cast<const f4v*>(a.gamma + d) + *reinterpret_cast<const f4v*>(a.beta + d);
+      if (mod) {
+        if (a.scale_off >= 0) y = y * (1.0f + Vec4<T>::load(mod + a.scale_off + d)) + Vec4<T>::load(mod + a.shift_off + d);
+        if (a.gate_off >= 0) y = y * Vec4<T>::load(mod + a.gate_off + d);
+      }
+      if (res) y = y + Vec4<T>::load(res + d);
+      Vec4<T>::store(out + d, y);
+    }
+  }
+}
+
+int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
+  if (a.rows <= 0) return 0;
+  if (a.D % 4 != 0 || a.D > RN_MAXIT * 256) return set_error(NOVA_ERR_SHAPE, "row_norm: D=%d unsupported (need D %% 4 == 0, D <= 2048)", a.D);
+  if (a.mod && (a.mod_ld % 4 || (a.scale_off >= 0 && (a.scale_off % 4 || a.shift_off % 4 || a.shift_off < 0)) ||
+                (a.gate_off >= 0 && a.gate_off % 4)))
+    return set_error(NOVA_ERR_SHAPE, "row_norm: modulation offsets must be multiples of 4");
+  if ((a.gamma == nullptr) != (a.beta == nullptr)) return set_error(NOVA_ERR_ARG, "row_norm: gamma/beta must come together");
+  dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
+  if (dtype == NOVA_BF16) hipLaunchKernelGGL(row_norm_kernel<bf16_t>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(row_norm_kernel<float>, grid, block, 0, st, a);
+  return check_launch("row_norm");
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE table: out[b][l][p] = (cos, sin)(pos_axis(p) * inv_freq[p]); rows l < pad are position 0.
+// pos [n_pos, 3] (t,h,w) f32 is batch independent (the reference expands one grid over the batch);
+// ids [nb, n_tok] int64 selects token -> position (gathered first-half sequence) or null (identity).
+__global__ void rope_table_kernel(const float* __restrict__ pos, const long long* __restrict__ ids,
+                                  float* __restrict__ table, int nb, int pad, int n_tok, int n_pos, int hd,
+                                  const float* __restrict__ inv_freq) {
+  const int half = hd / 2;
+  const long total = (long)nb * (pad + n_tok) * half;
+  const int n0 = (hd / 8) / 2, n1 = ((hd - hd / 8) / 2) / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % half);
+    const long bl = i / half;
+    const int l = (int)(bl % (pad + n_tok)), b = (int)(bl / (pad + n_tok));
+    float cs = 1.f, sn = 0.f;
+    if (l >= pad) {
+      const int tok = l - pad;
+      long idx = ids ? ids[(long)b * n_tok + tok] : tok;
+      idx = idx < 0 ? 0 : (idx >= n_pos ? n_pos - 1 : idx);
+      const int axis = p < n0 ? 0 : (p < n0 + n1 ? 1 : 2);
+      const float ang = pos[idx * 3 + axis] * inv_freq[p];
+      cs = cosf(ang);
+      sn = sinf(ang);
+    }
+    table[2 * i] = cs;
+    table[2 * i + 1] = sn;
+  }
+}
+
+int rope_table(const float* pos, const long long* ids, float* table, int nb, int pad, int n_tok, int n_pos, int hd,
+               const float* inv_freq, hipStream_t st) {
+  const long total = (long)nb * (pad + n_tok) * (hd / 2);
+  if (total <= 0) return 0;
+  const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(rope_table_kernel, dim3(blocks), dim3(256), 0, st, pos, ids, table, nb, pad, n_tok, n_pos, hd, inv_freq);
+  return check_launch("rope_table");
+}
+
+// ------------------------------------------------------------------------------------------
+// z0[b][n][:] = (W x[b][n] + bias) * (1 - m) + mask_token * m   (+ pos_embed[n][:])
+// x = patchified canvas [B, N, P] f32, W [D, P] in patchified order, m = mask[b][n] in {0, 1}.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_canvas_kernel(const float* __restrict__ canvas, const float* __restrict__ mask,
+                                                           const T* __restrict__ w, const float* __restrict__ bias,
+                                                           const T* __restrict__ mask_token, const T* __restrict__ pos_embed,
+                                                           T* __restrict__ z0, int N, int P, int D) {
+  __shared__ float xs[64];
+  const long tok = blockIdx.x;
+  if (threadIdx.x < P) xs[threadIdx.x] = canvas[tok * P + threadIdx.x];
+  __syncthreads();
+  const float m = mask[tok];
+  const int n = (int)(tok % N);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float e = bias[d];
+    for (int p = 0; p < P; ++p) e += xs[p] * to_f<T>(w[(long)d * P + p]);
+    float z = e * (1.0f - m) + to_f<T>(mask_token[d]) * m;
+    if (pos_embed) z += to_f<T>(pos_embed[(long)n * D + d]);
+    z0[tok * D + d] = from_f<T>(z);
+  }
+}
+
+int embed_canvas(const float* canvas, const float* mask, const void* w, const float* bias, const void* mask_token,
+                 const void* pos_embed, void* z0, int B, int N, int P, int D, int dtype, hipStream_t st) {
+  if ((long)B * N <= 0) return 0;
+  if (P > 64 || P <= 0) return set_error(NOVA_ERR_SHAPE, "embed_canvas: patch vector length %d unsupported (1..64)", P);
+  dim3 grid((unsigned)((long)B * N)), block(256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(embed_canvas_kernel<bf16_t>, grid, block, 0, st, canvas, mask, (const bf16_t*)w, bias,
+                       (const bf16_t*)mask_token, (const bf16_t*)pos_embed, (bf16_t*)z0, N, P, D);
+  else
+    hipLaunchKernelGGL(embed_canvas_kernel<float>, grid, block, 0, st, canvas, mask, (const float*)w, bias,
+                       (const float*)mask_token, (const float*)pos_embed, (float*)z0, N, P, D);
+  return check_launch("embed_canvas");
+}
+
+// ------------------------------------------------------------------------------------------
+// x[s][l] = l < Lp ? prefix[s][l] : tokens[s % B][ids ? ids[s % B][l - Lp] : l - Lp]
+// prefix rows of sequence s start at prefix + s * prefix_seq_rows * D; tokens of batch b at
+// tokens + b * tok_batch_rows * D (0 = shared by the whole batch).
+template <typename T>
+__global__ __launch_bounds__(256) void build_sequence_kernel(const T* __restrict__ prefix, long prefix_seq_rows,
+                                                             const T* __restrict__ tokens, long tok_batch_rows,
+                                                             const long long* __restrict__ ids, T* __restrict__ x,
+                                                             long rows, int B, int Lp, int n_sel, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int L = Lp + n_sel;
+  const long s = row / L;
+  const int l = (int)(row - s * L);
+  const T* src;
+  if (l < Lp) {
+    src = prefix + (s * prefix_seq_rows + l) * D;
+  } else {
+    const int b = (int)(s % B);
+    const long j = ids ? (long)ids[(long)b * n_sel + (l - Lp)] : (long)(l - Lp);
+    src = tokens + ((long)b * tok_batch_rows + j) * D;
+  }
+  T* dst = x + row * D;
+  constexpr int V = 16 / sizeof(T);
+  for (int d = lane * V; d < D; d += 64 * V) *reinterpret_cast<u4v*>(dst + d) = *reinterpret_cast<const u4v*>(src + d);
+}
+
+int build_sequence(const void* prefix, long prefix_seq_rows, const void* tokens, long tok_batch_rows,
+                   const long long* ids, void* x, int S, int B, int Lp, int n_sel, int D, int dtype, hipStream_t st) {
+  const long rows = (long)S * (Lp + n_sel);
+  if (rows <= 0) return 0;
+  const int V = dtype == NOVA_BF16 ? 8 : 4;
+  if (D % V) return set_error(NOVA_ERR_SHAPE, "build_sequence: D must be a multiple of %d", V);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(build_sequence_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)prefix, prefix_seq_rows,
+                       (const bf16_t*)tokens, tok_batch_rows, ids, (bf16_t*)x, rows, B, Lp, n_sel, D);
+  else
+    hipLaunchKernelGGL(build_sequence_kernel<float>, grid, block, 0, st, (const float*)prefix, prefix_seq_rows,
+                       (const float*)tokens, tok_batch_rows, ids, (float*)x, rows, B, Lp, n_sel, D);
+  return check_launch("build_sequence");
+}
+
+// x2[s][Lp + ids[s % B][j]] = x1[s][Lp + j]   (x1 rows per sequence: Lp + n_prev, x2: Lp + N)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_tokens_kernel(const T* __restrict__ x1, const long long* __restrict__ ids,
+                                                             T* __restrict__ x2, long rows, int B, int Lp, int N,
+                                                             int n_prev, int D) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long s = row / n_prev;
+  const int j = (int)(row - s * n_prev);
+  const int b = (int)(s % B);
+  const long tgt = (long)ids[(long)b * n_prev + j];
+  const T* src = x1 + (s * (Lp + n_prev) + Lp + j) * D;
+  T* dst = x2 + (s * (Lp + N) + Lp + tgt) * D;
+  constexpr int V = 16 / sizeof(T);
+  for (int d = lane * V; d < D; d += 64 * V) *reinterpret_cast<u4v*>(dst + d) = *reinterpret_cast<const u4v*>(src + d);
+}
+
+int scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B, int Lp, int N, int n_prev, int D,
+                   int dtype, hipStream_t st) {
+  const long rows = (long)S * n_prev;
+  if (rows <= 0) return 0;
+  const int V = dtype == NOVA_BF16 ? 8 : 4;
+  if (D % V) return set_error(NOVA_ERR_SHAPE, "scatter_tokens: D must be a multiple of %d", V);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(scatter_tokens_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x1, ids, (bf16_t*)x2, rows, B, Lp, N, n_prev, D);
+  else
+    hipLaunchKernelGGL(scatter_tokens_kernel<float>, grid, block, 0, st, (const float*)x1, ids, (float*)x2, rows, B, Lp, N, n_prev, D);
+  return check_launch("scatter_tokens");
+}
+
+// ------------------------------------------------------------------------------------------
+// out[r][:] = silu(a[r][:] + vec[:])     (SiLU(z) in front of every AdaLN projection, z = cond + time)
+template <typename T>
+__global__ __launch_bounds__(256) void silu_add_rows_kernel(const T* __restrict__ a, const T* __restrict__ vec,
+                                                            T* __restrict__ out, long total4, int D) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const int d = (int)(e % D);
+    f4v x = Vec4<T>::load(a + e);
+    if (vec) x = x + Vec4<T>::load(vec + d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = silu(x[j]);
+    Vec4<T>::store(out + e, x);
+  }
+}
+
+int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (D % 4) return set_error(NOVA_ERR_SHAPE, "silu_add_rows: D %% 4 != 0");
+  const long total4 = rows * D / 4;
+  const int blocks = (int)((total4 + 255) / 256 > 8192 ? 8192 : (total4 + 255) / 256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(silu_add_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)rowvec, (bf16_t*)out, total4, D);
+  else
+    hipLaunchKernelGGL(silu_add_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)rowvec, (float*)out, total4, D);
+  return check_launch("silu_add_rows");
+}
+
+// out[i][:] = [cos(t_i f_k) (k < F/2) ; sin(t_i f_k)]   f = time_freq table of the reference
+template <typename T>
+__global__ void timestep_freq_kernel(const float* __restrict__ t, const float* __restrict__ freq, T* __restrict__ out,
+                                     int n, int F) {
+  const int half = F / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n * half; i += gridDim.x * blockDim.x) {
+    const int row = i / half, kf = i % half;
+    const float ang = t[row] * freq[kf];
+    out[(long)row * F + kf] = from_f<T>(cosf(ang));
+    out[(long)row * F + half + kf] = from_f<T>(sinf(ang));
+  }
+}
+
+int timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, hipStream_t st) {
+  if (n <= 0) return 0;
+  const int total = n * (freq_dim / 2);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(timestep_freq_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, t, freq, (bf16_t*)out, n, freq_dim);
+  else
+    hipLaunchKernelGGL(timestep_freq_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, t, freq, (float*)out, n, freq_dim);
+  return check_launch("timestep_freq");
+}
+
+// u[s][j][:] = W x[s % B][j] + bias   (decoder patch embed of the noisy tokens being predicted)
+template <typename T>
+__global__ __launch_bounds__(256) void patch_embed_rows_kernel(const float* __restrict__ x, const T* __restrict__ w,
+                                                               const float* __restrict__ bias, T* __restrict__ out,
+                                                               int B, int n, int P, int D) {
+  __shared__ float xs[64];
+  const long row = blockIdx.x;  // s * n + j
+  const long s = row / n;
+  const int j = (int)(row - s * n), b = (int)(s % B);
+  if (threadIdx.x < P) xs[threadIdx.x] = x[((long)b * n + j) * P + threadIdx.x];
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float e = bias[d];
+    for (int p = 0; p < P; ++p) e += xs[p] * to_f<T>(w[(long)d * P + p]);
+    out[row * D + d] = from_f<T>(e);
+  }
+}
+
+int patch_embed_rows(const float* x, const void* w, const float* bias, void* out, int S, int B, int n, int P, int D,
+                     int dtype, hipStream_t st) {
+  if ((long)S * n <= 0) return 0;
+  if (P > 64 || P <= 0) return set_error(NOVA_ERR_SHAPE, "patch_embed_rows: patch vector length %d unsupported", P);
+  dim3 grid((unsigned)((long)S * n)), block(256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(patch_embed_rows_kernel<bf16_t>, grid, block, 0, st, x, (const bf16_t*)w, bias, (bf16_t*)out, B, n, P, D);
+  else
+    hipLaunchKernelGGL(patch_embed_rows_kernel<float>, grid, block, 0, st, x, (const float*)w, bias, (float*)out, B, n, P, D);
+  return check_launch("patch_embed_rows");
+}
+
+// Head projection + classifier-free guidance + Euler step for the n tokens of this AR step:
+//   pc = Wh h[b][j] + bh, pu = Wh h[B + b][j] + bh, v = cfg ? pu + g (pc - pu) : pc,  x[b][j] += dt v
+template <typename T>
+__global__ __launch_bounds__(256) void head_cfg_euler_kernel(const T* __restrict__ h, const T* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ x,
+                                                             long rows, int B, int n, int P, int D, float g, int cfg,
+                                                             float dt) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // b * n + j
+  if (row >= rows) return;
+  const T* hc = h + row * D;
+  const T* hu = h + ((long)B * n + row) * D;
+  for (int p = 0; p < P; ++p) {
+    float ac = 0.f, au = 0.f;
+    for (int d = lane * 4; d < D; d += 256) {
+      const f4v wv = Vec4<T>::load(w + (long)p * D + d);
+      const f4v c4 = Vec4<T>::load(hc + d);
+      ac += (wv[0] * c4[0] + wv[1] * c4[1]) + (wv[2] * c4[2] + wv[3] * c4[3]);
+      if (cfg) {
+        const f4v u4 = Vec4<T>::load(hu + d);
+        au += (wv[0] * u4[0] + wv[1] * u4[1]) + (wv[2] * u4[2] + wv[3] * u4[3]);
+      }
+    }
+    ac = wave_sum(ac) + bias[p];
+    float vv = ac;
+    if (cfg) {
+      au = wave_sum(au) + bias[p];
+      vv = au + (ac - au) * g;
+    }
+    if (lane == 0) x[row * P + p] += dt * vv;
+  }
+}
+
+int head_cfg_euler(const void* h, const void* w, const float* bias, float* x, int B, int n, int P, int D,
+                   float guidance, int cfg, float dt, int dtype, hipStream_t st) {
+  const long rows = (long)B * n;
+  if (rows <= 0) return 0;
+  if (D % 4) return set_error(NOVA_ERR_SHAPE, "head_cfg_euler: D %% 4 != 0");
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(head_cfg_euler_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)h, (const bf16_t*)w, bias, x, rows, B, n, P, D, guidance, cfg, dt);
+  else
+    hipLaunchKernelGGL(head_cfg_euler_kernel<float>, grid, block, 0, st, (const float*)h, (const float*)w, bias, x, rows, B, n, P, D, guidance, cfg, dt);
+  return check_launch("head_cfg_euler");
+}
+
+}  // namespace nova

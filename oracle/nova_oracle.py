@@ -1,0 +1,331 @@
+"""ORACLE — test infrastructure, NOT product code.
+
+A CPU restatement, in plain functional PyTorch (float32 or float64), of the arithmetic of the
+reference's generation hot path (zailaiyiwan123/NOVA_pointcloud, package `diffnext`). Every
+function cites the reference file:line it follows (paths relative to the reference root).
+
+Who may use this file: tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg, as the
+checker / the timed CPU baseline. The product (nova_pointcloud_amd/) never imports it.
+
+Parity pin: this restatement is checked against golden vectors produced in the build container
+by running the reference's OWN modules (tests/golden/make_golden.py imports
+diffnext.models.{vision_transformer,diffusion_mlp,embeddings,normalization,guidance_scaler} and
+diffnext.models.transformers.transformer_3d from /root/reference; they import without diffusers).
+The reference's schedulers and NOVAPipeline import `diffusers`, which is absent here, so
+`cosine_schedule`, `cfm_sigmas` and `encode_prompt_embeds` are restated from the source text and
+are "parity unpinned by execution" (pinned only by hand-derived values in tests/test_oracle.py).
+
+All tensors live on the CPU. Parameters come as a flat dict with the reference's state_dict keys.
+"""
+
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------
+# host-side schedule / sampler arithmetic
+# ----------------------------------------------------------------------------------------------
+def cosine_schedule(num_patches, num_inference_steps):
+    """diffnext/pipelines/nova/pipeline_nova.py:129-132 — tokens predicted at each AR step."""
+    k = num_inference_steps
+    mask_ratios = np.cos(0.5 * np.pi * np.arange(k + 1) / k)
+    mask_length = np.round(mask_ratios * num_patches).astype("int64")
+    return mask_length[:-1] - mask_length[1:]
+
+
+def cfm_sigmas(num_steps, shift=1.0, num_train_timesteps=1000):
+    """diffnext/schedulers/scheduling_cfm.py:40-49,92-104 — returns (timesteps f32[S], sigmas list[S+1])."""
+    train_t = np.arange(1, num_train_timesteps + 1, dtype="float32")[::-1]
+    train_sig = train_t / num_train_timesteps
+    train_sig = shift * train_sig / (1 + (shift - 1) * train_sig)  # __init__ uses the ctor shift
+    sigma_min, sigma_max = float(train_sig[-1]), float(train_sig[0])
+    t_max, t_min = sigma_max * num_train_timesteps, sigma_min * num_train_timesteps
+    timesteps = np.linspace(t_max, t_min, num_steps, dtype="float32")
+    sigmas = timesteps / num_train_timesteps
+    sigmas = shift * sigmas / (1 + (shift - 1) * sigmas)
+    return sigmas * num_train_timesteps, sigmas.tolist() + [0]
+
+
+def encode_prompt_embeds(text_weight, prompt_embeds, num_tokens):
+    """pipeline_nova.py:204-215 + embeddings.py:179-188 for the `prompt_embeds`, guidance > 1 path.
+
+    Returns [2B, num_tokens, token_dim]: rows 0..B-1 = padded prompts, B..2B-1 = unconditional.
+    """
+    x = text_weight[:num_tokens].expand(len(prompt_embeds), -1, -1).clone()
+    for i, p in enumerate(prompt_embeds):
+        x[i, : p.shape[0]] = torch.as_tensor(p).to(x.dtype)
+    neg = text_weight[: x.shape[1]].expand(x.shape[0], -1, -1)
+    return torch.cat([x, neg])
+
+
+# ----------------------------------------------------------------------------------------------
+# layers
+# ----------------------------------------------------------------------------------------------
+def layer_norm(x, w=None, b=None, eps=1e-5):
+    return F.layer_norm(x, x.shape[-1:], w, b, eps)
+
+
+def rope_weight(pos, head_dim, pad=0, ids=None, theta=10000.0):
+    """embeddings.py:45-67 RotaryEmbed3D.get_func — rotation table [bs, 1, pad+n, hd/2, 2, 2]."""
+    pos = pos.gather(1, ids.expand(-1, -1, 3)) if ids is not None else pos
+    pos = F.pad(pos, (0, 0, pad, 0), value=0) if pad else pos
+    weight = []
+    dims = [head_dim // 8] + [(head_dim - head_dim // 8) // 2] * 2
+    for i, grid in enumerate(pos.split(1, dim=-1)):
+        scale = torch.arange(0, dims[i], 2).float().div_(dims[i])  # float32 buffer in the reference
+        freq = torch.pow(theta, scale.float())
+        freq = grid * freq.reciprocal().unsqueeze(0)
+        freq = torch.stack([freq.cos(), -freq.sin(), freq.sin(), freq.cos()], dim=-1)
+        weight += [freq.view(freq.shape[:-1] + (2, 2))]
+    return torch.cat(weight, dim=-3).unsqueeze(1)
+
+
+def rope_pos(t, bs, hw):
+    """embeddings.py:52-57 RotaryEmbed3D.get_pos — (t, h, w) integer grid [bs, t*h*w, 3] float32."""
+    thw = [t] + list(hw)
+    pos = torch.zeros(thw + [3])
+    grid = [torch.arange(n) for n in thw]
+    for i in range(3):
+        pos[..., i].add_(grid[i].view([-1 if i == j else 1 for j in range(3)]))
+    return pos.view(1, -1, 3).expand(bs, -1, -1)
+
+
+def apply_rope(x, weight):
+    """embeddings.py:36-43 ApplyFunc — x [S,h,L,d]; adjacent-pair rotation."""
+    x = x.view(*x.shape[:-1], -1, 1, 2)
+    w = weight.to(dtype=x.dtype)
+    return w[..., 0].mul(x[..., 0]).add(w[..., 1] * x[..., 1]).flatten(3)
+
+
+def attention(p, pre, x, heads, rope=None):
+    """vision_transformer.py:51-64 Attention.forward (no KV cache, no mask)."""
+    S, L, D = x.shape
+    qkv = F.linear(x, p[pre + "qkv.weight"], p[pre + "qkv.bias"])
+    q, k, v = qkv.view(S, L, 3, heads, D // heads).permute(2, 0, 3, 1, 4).unbind(0)
+    if rope is not None:
+        q, k = apply_rope(q, rope), apply_rope(k, rope)
+    o = F.scaled_dot_product_attention(q, k, v)
+    return F.linear(o.transpose(1, 2).flatten(2), p[pre + "proj.weight"], p[pre + "proj.bias"])
+
+
+def vit_block(p, pre, x, heads, rope=None):
+    """vision_transformer.py:78-92 Block.forward — POST-norm: x = LN(f(x)) + x."""
+    a = attention(p, pre + "attn.", x, heads, rope)
+    x = layer_norm(a, p[pre + "norm1.weight"], p[pre + "norm1.bias"]) + x
+    m = F.linear(F.gelu(F.linear(x, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"])),
+                 p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
+    return layer_norm(m, p[pre + "norm2.weight"], p[pre + "norm2.bias"]) + x
+
+
+def vit_forward(p, pre, depth, heads, x, c=None, prev_ids=None, pos=None, pos_embed=None):
+    """vision_transformer.py:128-146 VisionTransformer.forward for token input x [S,N,D].
+
+    The MAE-style split: blocks[:depth/2] see [c ; known tokens], blocks[depth/2:] see
+    [c' ; full canvas]. pos_embed: abs-PE table [N, D] added in place of nn.Identity (:131).
+    """
+    head_dim = x.shape[-1] // heads
+    x = x + pos_embed if pos_embed is not None else x
+    x_masked = x
+    pe1 = pe2 = None
+    if pos is not None:  # prepare_pe :119-123
+        pad = 0 if c is None else c.size(1)
+        pe1 = pe2 = rope_weight(pos, head_dim, pad)
+        if prev_ids is not None:
+            pe1 = rope_weight(pos, head_dim, pad, prev_ids)
+    if prev_ids is not None:
+        x = x.gather(1, prev_ids.expand(-1, -1, x.size(-1)))
+    x = x if c is None else torch.cat([c, x], dim=1)
+    enc = depth // 2
+    for i in range(enc):
+        x = vit_block(p, f"{pre}blocks.{i}.", x, heads, pe1)
+    if prev_ids is not None and c is not None:
+        c, x = x.split((c.size(1), x.size(1) - c.size(1)), dim=1)
+    if prev_ids is not None:
+        x = x_masked.scatter(1, prev_ids.expand(-1, -1, x.size(-1)), x)
+        x = x if c is None else torch.cat([c, x], dim=1)
+    for i in range(enc, depth):
+        x = vit_block(p, f"{pre}blocks.{i}.", x, heads, pe2)
+    x = x if c is None else x[:, c.size(1):]
+    return layer_norm(x, p[pre + "norm.weight"], p[pre + "norm.bias"])
+
+
+def projector(p, pre, x):
+    """diffusion_mlp.py:26-36 Projector: fc2(SiLU(fc1(x)))."""
+    return F.linear(F.silu(F.linear(x, p[pre + "fc1.weight"], p[pre + "fc1.bias"])), p[pre + "fc2.weight"], p[pre + "fc2.bias"])
+
+
+def time_cond_embed(p, pre, timestep, z, freq_dim=256):
+    """diffusion_mlp.py:56-75 TimeCondEmbed."""
+    dim = freq_dim // 2
+    freq = torch.arange(dim, dtype=torch.float32).mul(-9.210340371976184 / dim).exp().unsqueeze(0)
+    emb = timestep.unsqueeze(-1).float() * freq
+    emb = torch.cat([emb.cos(), emb.sin()], dim=-1).to(dtype=z.dtype)
+    t = projector(p, pre + "timestep_proj.", emb)
+    return projector(p, pre + "condition_proj.", z) + (t.unsqueeze(1) if t.dim() == 2 else t)
+
+
+def adaln_zero(p, pre, x, z, num_stats, eps=1e-6):
+    """normalization.py:24-36 AdaLayerNormZero (no LoRA): returns (modulated x, remaining stats)."""
+    stats = F.linear(F.silu(z), p[pre + "proj.weight"], p[pre + "proj.bias"]).chunk(num_stats, dim=-1)
+    return layer_norm(x, None, None, eps) * (1 + stats[0]) + stats[1], stats[2:]
+
+
+def patch_embed(p, pre, x, patch):
+    """embeddings.py:160-166 PatchEmbed.forward on [B,C,H,W] -> [B,N,D] (conv k = s = patch)."""
+    return F.conv2d(x, p[pre + "proj.weight"], p[pre + "proj.bias"], stride=patch).flatten(2).transpose(1, 2)
+
+
+def patchify(x, patch):
+    """embeddings.py:152-154: [B,C,H,W] -> [B,N,p*p*C]."""
+    B, C, H, W = x.shape
+    x = x.view(B, C, H // patch, patch, W // patch, patch)
+    return x.permute(0, 2, 4, 3, 5, 1).flatten(1, 2).flatten(2, 4).contiguous()
+
+
+def unpatchify(x, patch, C, h, w):
+    """embeddings.py:156-158: [B,N,p*p*C] -> [B,C,H,W]."""
+    x = x.view(-1, h, w, patch, patch, C)
+    return x.permute(0, 5, 1, 3, 2, 4).flatten(2, 3).flatten(3, 4).contiguous()
+
+
+def diffusion_mlp(p, pre, depth, x_img, timestep, z, pred_ids, patch):
+    """diffusion_mlp.py:89-99 DiffusionMLP.forward with pred_ids: returns [S,N,p*p*C]."""
+    x = patch_embed(p, pre + "patch_embed.", x_img, patch)
+    o = patchify(x_img, patch)
+    x = x.gather(1, pred_ids.expand(-1, -1, x.size(-1)))
+    z = z.gather(1, pred_ids.expand(-1, -1, z.size(-1)))
+    z = time_cond_embed(p, pre + "time_cond_embed.", timestep, z)
+    for i in range(depth):
+        b = f"{pre}blocks.{i}."
+        h, (gate,) = adaln_zero(p, b + "norm1.", x, z, 3)
+        h = projector(p, b + "proj.", h)
+        x = layer_norm(h, p[b + "norm2.weight"], p[b + "norm2.bias"]) * gate + x
+    x = adaln_zero(p, pre + "norm.", x, z, 2)[0]
+    x = F.linear(x, p[pre + "head.weight"], p[pre + "head.bias"])
+    return o.scatter(1, pred_ids.expand(-1, -1, x.size(-1)), x)
+
+
+def sincos_2d(dim, h, w):
+    """embeddings.py:70-88 PosEmbed.get_space_embed at base size (h, w): [h*w, dim] float32."""
+    freq_hw = 1 / (10000 ** (torch.arange(dim // 4, dtype=torch.float32) / (dim // 4)))
+    grid_h = torch.arange(h, dtype=torch.float32)
+    grid_w = torch.arange(w, dtype=torch.float32)
+    grid_w, grid_h = torch.meshgrid(grid_w, grid_h, indexing="xy")
+    freq_w, freq_h = [g.reshape(-1, 1) * freq_hw.unsqueeze(0) for g in (grid_w, grid_h)]
+    return torch.cat([freq_w.sin(), freq_w.cos(), freq_h.sin(), freq_h.cos()], dim=-1)
+
+
+def video_time_embed(p, pre, t, base_t):
+    """embeddings.py:103-111 VideoPosEmbed.get_time_embed: [t, 1, D]."""
+    freq_t = 1 / (10000 ** (torch.arange(128, dtype=torch.float32).unsqueeze(0) / 128))
+    grid = torch.arange(t, dtype=torch.float32) / (t / base_t)
+    f = grid.view(-1, 1, 1).mul(freq_t)
+    sincos = torch.cat([f.sin(), f.cos()], dim=-1).to(p[pre + "norm.weight"].dtype)
+    h = F.linear(F.silu(F.linear(sincos, p[pre + "time_proj.0.weight"], p[pre + "time_proj.0.bias"])),
+                 p[pre + "time_proj.2.weight"], p[pre + "time_proj.2.bias"])
+    return layer_norm(h, p[pre + "norm.weight"], p[pre + "norm.bias"])
+
+
+# ----------------------------------------------------------------------------------------------
+# the generation loop
+# ----------------------------------------------------------------------------------------------
+class Config(dict):
+    """Geometry of a model instance (what NOVATransformer3DModel.__init__ derives, transformer_nova.py:59-102)."""
+
+    __getattr__ = dict.__getitem__
+
+
+def make_config(image_dim, latent_hw, patch, embed_dim, heads, video_depth, image_depth, decoder_depth,
+                text_token_len, rotary=True, video_base_t=1):
+    H, W = latent_hw
+    return Config(image_dim=image_dim, latent_hw=(H, W), patch=patch, video_patch=patch * 2, embed_dim=embed_dim,
+                  heads=heads, video_depth=video_depth, image_depth=image_depth, decoder_depth=decoder_depth,
+                  text_token_len=text_token_len, rotary=rotary, video_base_t=video_base_t,
+                  image_hw=(H // patch, W // patch), video_hw=(H // (2 * patch), W // (2 * patch)))
+
+
+def generate(p, cfg, prompt, num_preds, num_diffusion_steps=25, guidance_scale=5.0, generator=None,
+             shift=1.0, dtype=torch.float32, u_dist=None, noises=None, trace=None):
+    """Transformer3DModel.forward in eval mode for T = 1 (transformer_3d.py:63-77,102-164,192-200).
+
+    prompt: [2B, Lt, token_dim] from encode_prompt_embeds. Returns x [B, C, 1, H, W].
+    RNG contract: one uniform_ [B,N,1] (embeddings.py:265) then one normal_ [B,C,H,W] per AR step
+    (transformer_3d.py:131), all from `generator`; `u_dist` / `noises` replay pre-drawn values
+    instead (used to compare dtypes / devices on identical noise). `trace` (dict) collects
+    intermediates for the tests.
+    """
+    p = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in p.items()}
+    D, heads, C, patch = cfg.embed_dim, cfg.heads, cfg.image_dim, cfg.patch
+    (H, W), (h, w), (hv, wv) = cfg.latent_hw, cfg.image_hw, cfg.video_hw
+    N, Nv = h * w, hv * wv
+    S = prompt.shape[0]
+    cfg_on = guidance_scale > 1
+    B = S // 2 if cfg_on else S
+    expand = (lambda t: torch.cat([t, t])) if cfg_on else (lambda t: t)
+
+    # preprocess :63-77 — TextEmbed.forward embeddings.py:203-206
+    c_txt = layer_norm(F.linear(prompt.to(dtype), p["text_embed.proj.weight"], p["text_embed.proj.bias"]),
+                       p["text_embed.norm.weight"], p["text_embed.norm.bias"])
+    timesteps, sigmas = cfm_sigmas(num_diffusion_steps, shift)
+
+    # generate_video :135-164, t = 0 only
+    bos, mask_token = p["mask_embed.bos_token"], p["mask_embed.mask_token"]
+    cv = bos.expand(B, Nv, D).clone()  # :152-153 patch_embed output overwritten by bos_token
+    if cfg.rotary:
+        pos_v = rope_pos(1, 1, cfg.video_hw)
+        img_pe = None
+    else:
+        cv = cv + video_time_embed(p, "video_pos_embed.", 1, cfg.video_base_t)[0]  # :154 add_(time_embed[t])
+        cv = cv + sincos_2d(D, hv, wv).to(dtype)  # VideoPosEmbed.forward embeddings.py:113-115
+        pos_v = None
+        img_pe = sincos_2d(D, h, w).to(dtype)
+    cv = expand(cv)
+    c = vit_forward(p, "video_encoder.", cfg.video_depth, heads, cv, c_txt, None, pos_v)
+    if trace is not None:
+        trace["c"] = c.clone()
+
+    # generate_frame :115-133
+    x = torch.zeros(B, C, H, W, dtype=dtype)
+    noise = torch.empty(B, C, H, W, dtype=dtype)
+    mask = torch.ones(B, N, 1, dtype=dtype)
+    pos = rope_pos(1, S, cfg.image_hw) if cfg.rotary else None
+    if u_dist is None:
+        u_dist = torch.empty_like(mask).uniform_(generator=generator)
+    order = u_dist.argsort(dim=1)  # embeddings.py:265-266
+    if trace is not None:
+        trace["order"] = order.clone()
+        trace["z"] = []
+    pred_pos, prev_ids = 0, None
+    for i, n in enumerate([int(v) for v in num_preds if v > 0]):
+        z = patch_embed(p, "image_encoder.patch_embed.", x, patch)
+        z = z * (1 - mask) + mask_token * mask  # embeddings.py:272-274 with the mask BEFORE this step's update
+        pred_ids = order[:, pred_pos:pred_pos + n]
+        pred_mask = torch.zeros_like(mask).scatter_(1, pred_ids, 1)
+        pred_pos, mask = pred_pos + n, mask * (1 - pred_mask)
+        pred_ids = expand(pred_ids)
+        prev_ids = prev_ids if i else pred_ids.new_empty((pred_ids.size(0), 0, 1))
+        z = vit_forward(p, "image_encoder.", cfg.image_depth, heads, expand(z), c, prev_ids, pos, img_pe)
+        if trace is not None:
+            trace["z"].append(z.clone())
+        prev_ids = torch.cat([prev_ids, pred_ids], dim=1)
+        if noises is None:
+            noise.normal_(generator=generator)
+        else:
+            noise = noises[i].to(dtype)
+        # denoise :102-113 (2-pass CFG, no truncation, no renorm)
+        xt = noise
+        for j, t in enumerate(timesteps):
+            timestep = torch.as_tensor(t).expand(z.shape[0])
+            pred = diffusion_mlp(p, "image_decoder.", cfg.decoder_depth, expand(xt), timestep, z, pred_ids, patch)
+            if cfg_on:  # guidance_scaler.py:86-87
+                cond, uncond = pred.chunk(2)
+                pred = uncond + (cond - uncond) * guidance_scale
+            pred = unpatchify(pred, patch, C, h, w)
+            dt = sigmas[j + 1] - sigmas[j]  # scheduling_cfm.py:134-135
+            xt = pred * dt + xt
+        sample = patchify(xt, patch)
+        x = x + unpatchify(sample * pred_mask, patch, C, h, w)  # :133
+    return x.unsqueeze(2)

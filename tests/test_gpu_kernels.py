@@ -1,0 +1,238 @@
+"""Per-kernel numerics of libnova_hip.so against plain PyTorch fp32 math (GPU box only).
+
+Every call goes through the C ABI (ctypes). Tolerances: f32 mode runs on exact-f32 MFMA so only
+summation order differs (1e-5 relative to the row scale); bf16 mode is bounded by bf16 storage
+rounding of inputs/outputs (2^-8 relative) with f32 accumulation.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.6e-2
+
+
+def relerr(got, ref):
+    got, ref = got.float(), ref.float()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (389, 384, 512), (1, 128, 256), (1024, 1024, 1024)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_bias_act(hip, dtype, M, N, K, act):
+    a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    bias = rnd(N, seed=3)
+    out = hip.gemm_bias_act(a, w, bias, act)
+    ref = a.float() @ w.float().T + bias
+    ref = [lambda x: x, torch.nn.functional.gelu, torch.nn.functional.silu][act](ref)
+    assert out.shape == (M, N) and out.dtype == dtype
+    assert relerr(out, ref) < tol(dtype)
+
+
+def test_gemm_layout_asymmetric(hip):
+    """A = I against an asymmetric W catches a transposed C write or a wrong fragment map."""
+    K = N = 128
+    a = torch.eye(K, device=DEV)
+    w = (torch.arange(N * K, device=DEV, dtype=torch.float32).view(N, K) % 251) - 125.0
+    for dtype in DTYPES:
+        out = hip.gemm_bias_act(a.to(dtype), w.to(dtype), None, 0)
+        assert torch.equal(out.float(), w.T.contiguous())
+
+
+def test_gemm_rejects_bad_shapes(hip):
+    a, w = rnd(8, 64), rnd(100, 64)
+    with pytest.raises(hip.NovaHipError):
+        hip.gemm_bias_act(a, w)
+
+
+def ref_rope_table(pos, ids, pad, hd, theta=10000.0):
+    """embeddings.py:59-67 restated for the test: returns cos, sin [nb, pad + n, hd/2]."""
+    if ids is not None:
+        pos = pos[ids]  # [nb, n, 3]
+    else:
+        pos = pos[None]
+    pos = torch.nn.functional.pad(pos, (0, 0, pad, 0))
+    dims = [hd // 8] + [(hd - hd // 8) // 2] * 2
+    ang = []
+    for i, rd in enumerate(dims):
+        scale = torch.arange(0, rd, 2, device=pos.device).float() / rd
+        ang.append(pos[..., i:i + 1] * torch.pow(theta, scale).reciprocal())
+    ang = torch.cat(ang, -1)
+    return ang.cos(), ang.sin()
+
+
+def inv_freq(hd, theta=10000.0):
+    dims = [hd // 8] + [(hd - hd // 8) // 2] * 2
+    return torch.cat([torch.pow(theta, torch.arange(0, rd, 2).float() / rd).reciprocal() for rd in dims]).to(DEV)
+
+
+def grid_pos(h, w):
+    t = torch.zeros(h * w)
+    hh = torch.arange(h).repeat_interleave(w).float()
+    ww = torch.arange(w).repeat(h).float()
+    return torch.stack([t, hh, ww], -1).to(DEV)
+
+
+def test_rope_table(hip):
+    hd, pad, nb = 64, 5, 3
+    pos = grid_pos(6, 7)
+    g = torch.Generator().manual_seed(0)
+    ids = torch.stack([torch.randperm(42, generator=g)[:17] for _ in range(nb)]).to(DEV)
+    for use_ids in (ids, None):
+        tab = hip.rope_table(pos, use_ids, pad, inv_freq(hd), nb, hd)
+        cos, sin = ref_rope_table(pos, use_ids, pad, hd)
+        cos, sin = cos.expand(nb, -1, -1), sin.expand(nb, -1, -1)
+        assert torch.allclose(tab[..., 0], cos, atol=2e-6) and torch.allclose(tab[..., 1], sin, atol=2e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_qkv_rope(hip, dtype):
+    S, L, D, heads, nb = 4, 37, 128, 2, 2
+    hd = D // heads
+    x, w, b = rnd(S * L, D, dtype=dtype), rnd(3 * D, D, dtype=dtype, scale=D ** -0.5, seed=5), rnd(3 * D, seed=6)
+    pos = grid_pos(8, 8)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.stack([torch.randperm(64, generator=g)[: L - 7] for _ in range(nb)]).to(DEV)
+    tab = hip.rope_table(pos, ids, 7, inv_freq(hd), nb, hd)
+    out = hip.qkv_rope(x, w, b, tab, S, L, heads)
+    ref = (x.float() @ w.float().T + b).view(S, L, 3, heads, hd)
+    cos = tab[..., 0].repeat(S // nb, 1, 1)[:, :, None, None, :]  # sequence s uses table s % nb
+    sin = tab[..., 1].repeat(S // nb, 1, 1)[:, :, None, None, :]
+    qk = ref[:, :, :2].reshape(S, L, 2, heads, hd // 2, 2)
+    x0, x1 = qk[..., 0], qk[..., 1]
+    rot = torch.stack([cos * x0 - sin * x1, sin * x0 + cos * x1], -1).view(S, L, 2, heads, hd)
+    ref = torch.cat([rot, ref[:, :, 2:]], 2).view(S * L, 3 * D)
+    assert relerr(out, ref) < tol(dtype)
+    out2 = hip.qkv_rope(x, w, b, None, S, L, heads)
+    assert relerr(out2, x.float() @ w.float().T + b) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,heads,L", [(1, 1, 64), (2, 2, 128), (2, 3, 200), (1, 2, 333), (3, 1, 31), (1, 4, 769)])
+def test_attention(hip, dtype, S, heads, L):
+    hd = 64
+    D = heads * hd
+    qkv = rnd(S * L, 3 * D, dtype=dtype, seed=7)
+    out = hip.attn_fwd_packed(qkv, S, L, heads)
+    q, k, v = qkv.float().view(S, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S * L, D)
+    assert relerr(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_spiky_rows(hip, dtype):
+    """Force large running-max jumps late in the key stream (online-softmax rescale path)."""
+    S, heads, L, hd = 1, 1, 320, 64
+    qkv = rnd(S * L, 3 * hd, dtype=dtype, seed=9)
+    q = qkv[:, :hd].float()
+    qkv[300, hd:2 * hd] = (q[5] * 4).to(dtype)   # key 300 aligned with query 5
+    qkv[170, hd:2 * hd] = (q[77] * 3).to(dtype)
+    out = hip.attn_fwd_packed(qkv, S, L, heads)
+    qq, k, v = qkv.float().view(S, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = torch.nn.functional.scaled_dot_product_attention(qq, k, v).transpose(1, 2).reshape(S * L, hd)
+    assert relerr(out, ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [128, 768, 1024, 1536])
+def test_row_norm_variants(hip, dtype, D):
+    rows = 37
+    x, res = rnd(rows, D, dtype=dtype, seed=11), rnd(rows, D, dtype=dtype, seed=12)
+    gamma, beta = rnd(D, seed=13) + 1, rnd(D, seed=14)
+    mod = rnd(rows, 5 * D, dtype=dtype, scale=0.5, seed=15)
+    ln = lambda t, eps: torch.nn.functional.layer_norm(t.float(), (D,), None, None, eps)
+    # ViT post-norm residual, in place on the residual stream
+    r = res.clone()
+    hip.row_norm(x, out=r, gamma=gamma, beta=beta, res=r, eps=1e-5)
+    assert relerr(r, ln(x, 1e-5) * gamma + beta + res.float()) < tol(dtype)
+    # AdaLN-Zero modulate
+    o = hip.row_norm(x, mod=mod, scale_off=D, shift_off=2 * D, eps=1e-6)
+    assert relerr(o, ln(x, 1e-6) * (1 + mod[:, D:2 * D].float()) + mod[:, 2 * D:3 * D].float()) < tol(dtype)
+    # gate * LN_affine + residual
+    o = hip.row_norm(x, gamma=gamma, beta=beta, mod=mod, gate_off=4 * D, res=res, eps=1e-5)
+    assert relerr(o, (ln(x, 1e-5) * gamma + beta) * mod[:, 4 * D:].float() + res.float()) < tol(dtype)
+    # gathered rows
+    idx = torch.tensor([5, 0, 36, 36, 7], dtype=torch.int32, device=DEV)
+    o = hip.row_norm(x, gamma=gamma, beta=beta, gather=idx, eps=1e-5)
+    assert relerr(o, (ln(x, 1e-5) * gamma + beta)[idx.long()]) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_token_plumbing(hip, dtype):
+    B, N, P, D, Lp, S = 2, 24, 3, 128, 5, 4
+    canvas, mask = rnd(B, N, P, seed=20), (torch.rand(B, N, device=DEV) > 0.5).float()
+    w, b, tok, pe = rnd(D, P, dtype=dtype), rnd(D, seed=21), rnd(1, D, dtype=dtype, seed=22), rnd(N, D, dtype=dtype, seed=23)
+    z0 = torch.empty(B, N, D, dtype=dtype, device=DEV)
+    c = hip.dtype_code(dtype)
+    for pos_embed in (None, pe):
+        hip.call("nova_embed_canvas", hip.ptr(canvas), hip.ptr(mask), hip.ptr(w), hip.ptr(b), hip.ptr(tok),
+                 hip.ptr(pos_embed), hip.ptr(z0), B, N, P, D, c, hip.stream_ptr())
+        e = canvas @ w.float().T + b
+        ref = e * (1 - mask[..., None]) + tok.float() * mask[..., None]
+        ref = ref + pe.float() if pos_embed is not None else ref
+        assert relerr(z0, ref) < tol(dtype)
+    prefix = rnd(S, Lp, D, dtype=dtype, seed=24)
+    g = torch.Generator().manual_seed(3)
+    ids = torch.stack([torch.randperm(N, generator=g)[:9] for _ in range(B)]).to(DEV)
+    x1 = torch.empty(S, Lp + 9, D, dtype=dtype, device=DEV)
+    hip.call("nova_build_sequence", hip.ptr(prefix), Lp, hip.ptr(z0), N, hip.ptr(ids), hip.ptr(x1), S, B, Lp, 9, D, c,
+             hip.stream_ptr())
+    zz = torch.cat([z0, z0])
+    ref1 = torch.cat([prefix, zz.gather(1, torch.cat([ids, ids])[..., None].expand(-1, -1, D))], 1)
+    assert torch.equal(x1, ref1)
+    x2 = torch.empty(S, Lp + N, D, dtype=dtype, device=DEV)
+    hip.call("nova_build_sequence", hip.ptr(x1), Lp + 9, hip.ptr(z0), N, None, hip.ptr(x2), S, B, Lp, N, D, c,
+             hip.stream_ptr())
+    x1m = x1 * 2
+    hip.call("nova_scatter_tokens", hip.ptr(x1m), hip.ptr(ids), hip.ptr(x2), S, B, Lp, N, 9, D, c, hip.stream_ptr())
+    ref2 = torch.cat([x1[:, :Lp], zz.scatter(1, torch.cat([ids, ids])[..., None].expand(-1, -1, D), x1m[:, Lp:])], 1)
+    assert torch.equal(x2, ref2)
+    # shared token rows (video-encoder bos canvas): tok_batch_rows = 0
+    shared = rnd(7, D, dtype=dtype, seed=25)
+    xv = torch.empty(S, Lp + 7, D, dtype=dtype, device=DEV)
+    hip.call("nova_build_sequence", hip.ptr(prefix), Lp, hip.ptr(shared), 0, None, hip.ptr(xv), S, B, Lp, 7, D, c,
+             hip.stream_ptr())
+    assert torch.equal(xv, torch.cat([prefix, shared.expand(S, -1, -1)], 1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_decoder_glue(hip, dtype):
+    B, n, P, D, S = 3, 5, 3, 256, 6
+    c = hip.dtype_code(dtype)
+    a, vec = rnd(S * n, D, dtype=dtype, seed=30), rnd(D, dtype=dtype, seed=31)
+    out = torch.empty_like(a)
+    hip.call("nova_silu_add_rows", hip.ptr(a), hip.ptr(vec), hip.ptr(out), S * n, D, c, hip.stream_ptr())
+    assert relerr(out, torch.nn.functional.silu(a.float() + vec.float())) < tol(dtype)
+    t = torch.tensor([1000.0, 500.25, 1.0], device=DEV)
+    freq = torch.arange(128, dtype=torch.float32, device=DEV).mul(-math.log(10000.0) / 128).exp()
+    fe = torch.empty(3, 256, dtype=dtype, device=DEV)
+    hip.call("nova_timestep_freq", hip.ptr(t), hip.ptr(freq), hip.ptr(fe), 3, 256, c, hip.stream_ptr())
+    emb = t[:, None] * freq[None]
+    assert (fe.float() - torch.cat([emb.cos(), emb.sin()], -1)).abs().max() < (1e-4 if dtype == torch.float32 else 8e-3)
+    x = rnd(B, n, P, seed=32)
+    w, b = rnd(D, P, dtype=dtype, seed=33), rnd(D, seed=34)
+    u = torch.empty(S * n, D, dtype=dtype, device=DEV)
+    hip.call("nova_patch_embed_rows", hip.ptr(x), hip.ptr(w), hip.ptr(b), hip.ptr(u), S, B, n, P, D, c, hip.stream_ptr())
+    assert relerr(u, torch.cat([x, x]).view(S * n, P) @ w.float().T + b) < tol(dtype)
+    h = rnd(S * n, D, dtype=dtype, seed=35)
+    hw, hb = rnd(P, D, dtype=dtype, scale=D ** -0.5, seed=36), rnd(P, seed=37)
+    for cfg, g in ((1, 5.0), (0, 1.0)):
+        xx = x.clone()
+        hip.call("nova_head_cfg_euler", hip.ptr(h), hip.ptr(hw), hip.ptr(hb), hip.ptr(xx), B, n, P, D, g, cfg, -0.04, c,
+                 hip.stream_ptr())
+        pred = (h.float() @ hw.float().T + hb).view(S, n, P)
+        v = pred[B:] + (pred[:B] - pred[B:]) * g if cfg else pred[:B]
+        assert relerr(xx, x + (-0.04) * v) < tol(dtype)
