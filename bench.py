@@ -1,0 +1,217 @@
+"""Benchmark of the NOVA point-set generation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full `NOVAPipeline.__call__` (prompt embeddings -> point sets) of the workload
+BASELINE.json's metric is quoted on: NOVA-d48w1024 (0.6B), 2048 points per sample, 64 AR steps x 25
+diffusion steps, CFG on, bf16, batch 32 PER GPU (weak scaling; configs[2] at N=1, configs[3] at
+N=8). Prompts are synthetic and already resident in HBM; weights are random-init (no network).
+Rank 0 prints ONE JSON line: whole-job generated points/s plus
+  roofline      the dominant kernel family (MFMA GEMM / attention), timed live with HIP events on the
+                launch stream inside the timed region (nova_prof_*), against the 2.5 PFLOP/s dense
+                bf16 MFMA peak of MI355X_MICROARCH.md
+  cpu_baseline  the oracle (oracle/nova_oracle.py, a port of the reference's CPU path) timed on the
+                host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "nova_pointcloud_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+WORKLOADS = {
+    # name: (width, heads, latent H, W, per-GPU batch)   N = H*W points, Nv = N/4 condition tokens
+    "d48w1024_2048pts_b32": (1024, 16, 32, 64, 32),
+    "d48w768_1024pts_b8": (768, 12, 32, 32, 8),
+    "d48w768_256pts_b1": (768, 12, 16, 16, 1),
+}
+
+
+def flops_per_sample(D, N, Nv, Lt, schedule, S, P=3, token_dim=2560):
+    """Algorithmic FLOPs of one generated sample with CFG (SURVEY §8d formula, exact integer schedule)."""
+    blk = lambda L: 24.0 * D * D * L + 4.0 * L * L * D
+    total = 16 * blk(Lt + Nv) + Lt * 2.0 * token_dim * D
+    done = 0
+    for n in schedule:
+        total += 16 * blk(Nv + done) + 16 * blk(Nv + N)
+        total += S * n * (68.0 * D * D + 4.0 * D * P)
+        done += n
+    return 2.0 * total
+
+
+def build_pipeline(width, heads, H, W, dtype, device, seed=0):
+    from diffnext.models.transformers.transformer_nova import NOVATransformer3DModel
+    from diffnext.pipelines import NOVAPipeline
+    from diffnext.schedulers import FlowMatchEulerDiscreteScheduler
+
+    torch.manual_seed(seed)
+    model = NOVATransformer3DModel(
+        image_dim=3, image_size=(16 * H, 16 * W), image_stride=16, text_token_dim=2560, text_token_len=256,
+        image_base_size=[H, W], video_base_size=[1, H // 2, W // 2], rotary_pos_embed=True,
+        arch=(f"vit_d16w{width}", f"vit_d32w{width}", f"mlp_d6w{width}"))
+    model = model.to(dtype=dtype).to(device).eval()
+    return NOVAPipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler(num_train_timesteps=1000, shift=1.0))
+
+
+def synthetic_prompts(B, device, dtype, seed=1234):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(8, 65, (B,), generator=g).tolist()
+    return [(0.02 * torch.randn(n, 2560, generator=g)).to(device=device, dtype=dtype) for n in lens]
+
+
+def host_cores():
+    """CPU share of this process: cgroup quota if set, else the affinity mask (never the machine's core count)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(pipe, width, heads, H, W, threads):
+    """Oracle (port of the reference CPU path) on a bounded sample of the SAME architecture: B=1, the first two set
+    sizes of a 2-step cosine schedule over all N points, 2 diffusion steps; converted to points/s of the full
+    workload by the FLOP ratio."""
+    from oracle import nova_oracle as O
+
+    torch.set_num_threads(threads)
+    N, Nv = H * W, (H // 2) * (W // 2)
+    sd = {k: v.detach().float().cpu() for k, v in pipe.transformer.state_dict().items()}
+    cfg = O.make_config(3, (H, W), 1, width, heads, 16, 32, 6, 256, rotary=True)
+    g = torch.Generator().manual_seed(5)
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], [0.02 * torch.randn(24, 2560, generator=g)], 256)
+    sched, S = O.cosine_schedule(N, 2), 2
+    t0 = time.time()
+    with torch.no_grad():
+        O.generate(sd, cfg, prompt, sched, num_diffusion_steps=S, guidance_scale=5.0, generator=g)
+    dt = time.time() - t0
+    sample_flops = flops_per_sample(width, N, Nv, 256, [int(v) for v in sched], S)
+    full = flops_per_sample(width, N, Nv, 256, [int(v) for v in O.cosine_schedule(N, 64) if v > 0], 25)
+    tflops = sample_flops / dt / 1e12
+    return {"value": round(tflops * 1e12 / (full / N), 3), "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32, same d48w{width} weights, B=1, {N} points, 2 AR x 2 diffusion steps "
+                      f"({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {tflops:.3f} TFLOP/s), scaled by FLOPs to 64x25"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="d48w1024_2048pts_b32", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = workload default)")
+    ap.add_argument("--ar-steps", type=int, default=64)
+    ap.add_argument("--diffusion-steps", type=int, default=25)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from nova_pointcloud_amd import hip
+    from diffnext.pipelines.nova.pipeline_nova import cosine_set_sizes, points_from_latents
+
+    width, heads, H, W, B = WORKLOADS[args.workload]
+    B = args.batch or B
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    pipe = build_pipeline(width, heads, H, W, dtype, device)
+    prompts = synthetic_prompts(B, device, dtype, seed=1234 + rank)  # every rank generates its own shard
+    gen = torch.Generator(device=device).manual_seed(rank)
+    N, Nv = H * W, (H // 2) * (W // 2)
+    gathered = torch.empty(world * B, N, 3, dtype=torch.float32, device=device) if world > 1 else None
+
+    def step():
+        out = pipe(prompt_embeds=prompts, num_inference_steps=args.ar_steps, num_diffusion_steps=args.diffusion_steps,
+                   guidance_scale=5, generator=gen, output_type="latent", disable_progress_bar=True)
+        pts = points_from_latents(out.frames).float().contiguous()  # [B, N, 3]
+        if world > 1:  # the path's only exchange: gather the generated point sets of all shards (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered, pts)
+            return gathered
+        return pts
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        pts = step()
+    fence()
+    hip.prof_enable(True)
+    hip.prof_collect()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pts = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = hip.prof_collect()
+    hip.prof_enable(False)
+    assert torch.isfinite(pts).all(), "non-finite points generated"
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    if rank == 0:
+        schedule = [int(v) for v in cosine_set_sizes(N, args.ar_steps) if v > 0]
+        fl = flops_per_sample(width, N, Nv, 256, schedule, args.diffusion_steps)
+        value = world * B * N * args.steps / elapsed
+        e2e_tflops = value / N * fl / 1e12 / world  # per GPU
+        fams = {k: {"ms": round(ms, 2), "launches": n,
+                    "rate": round(wk / ms / (1e6 if k == "row_norm" else 1e9), 2) if ms > 0 else 0.0,
+                    "unit": "GB/s" if k == "row_norm" else "TFLOP/s"} for k, (ms, wk, n) in prof.items() if n}
+        mfma = {k: v for k, v in fams.items() if k != "row_norm"}
+        dom = max(mfma, key=lambda k: mfma[k]["ms"])
+        rec = {
+            "metric": "generated points/sec/node, NOVA-d48w1024 @2048 pts, 64-step sample",
+            "value": round(value, 2), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": args.workload, "points_per_sample": N, "ar_steps": len(schedule),
+                       "diffusion_steps": args.diffusion_steps, "batch_per_gpu": B, "global_batch": world * B,
+                       "guidance": "cfg 2-pass", "sharding": f"batch rows over {world} GPU(s), all_gather of points"},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["rate"], "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(mfma[dom]["rate"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(mfma[dom]["ms"] / mfma[dom]["launches"], 4),
+                         "share_of_step_time": round(mfma[dom]["ms"] / 1e3 / elapsed, 3)},
+            "end_to_end": {"tflops_per_gpu": round(e2e_tflops, 1), "frac_of_mfma_peak": round(e2e_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
+                           "gflop_per_point": round(fl / N / 1e9, 2)},
+            "kernels": fams,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(pipe, width, heads, H, W, threads=host_cores())
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,6 +45,15 @@ const char* nova_last_error(void);
 /* 0 when a gfx950 device is current, NOVA_ERR_DEVICE otherwise (checked once by the loader). */
 int nova_check_device(void);
 
+/* ---- measurement hooks (bench.py): HIP-event timing of the GEMM / attention / row-norm launches on
+ * the stream they are launched on. nova_prof_enable(1) starts recording; nova_prof_collect waits
+ * for the recorded events and returns, per slot, summed milliseconds, summed algorithmic work
+ * (FLOPs for slots 0-4, bytes for slot 5) and launch counts, then clears the record.
+ * Slots: 0 gemm+bias, 1 gemm+bias+GELU, 2 gemm+bias+SiLU, 3 qkv gemm+RoPE, 4 attention, 5 row_norm. */
+#define NOVA_PROF_SLOTS 6
+int nova_prof_enable(int on);
+int nova_prof_collect(double* ms, double* work, long long* launches, int slots);
+
 /* ---- projection GEMM -----------------------------------------------------------------------
  * out[M,N] = act(A[M,K] * W[N,K]^T + bias[N])        W in nn.Linear layout.
  * Replaces nn.Linear (+ nn.GELU() / nn.SiLU()) at vision_transformer.py:33-38 (MLP.fc1/fc2),

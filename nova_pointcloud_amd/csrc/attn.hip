@@ -303,6 +303,7 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (S > 65535 || heads > 65535) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
   const float c = scale * 1.4426950408889634f;
   dim3 grid((Lq + 127) / 128, heads, S), block(256);
+  ProfScope prof(PROF_ATTN, 4.0 * S * heads * (double)Lq * Lk * hd, st);
   if (dtype == NOVA_BF16) {
     hipLaunchKernelGGL(attn_bf16_hd64, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
                        (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);

@@ -4,6 +4,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <utility>
+#include <vector>
 #include "common.h"
 #include "nova_internal.h"
 
@@ -23,6 +25,32 @@ int check_launch(const char* what) {
   const hipError_t e = hipGetLastError();
   if (e == hipSuccess) return 0;
   return set_error(NOVA_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+// ---- profiling: event pairs recorded around selected launches, summed on nova_prof_collect()
+struct ProfRec { hipEvent_t a, b; int slot; double work; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+ProfScope::ProfScope(int slot, double work, hipStream_t s) : idx(-1), st(s) {
+  if (!g_prof_on) return;
+  ProfRec r;
+  if (!g_prof_pool.empty()) {
+    r.a = g_prof_pool.back().first;
+    r.b = g_prof_pool.back().second;
+    g_prof_pool.pop_back();
+  } else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+    return;
+  }
+  r.slot = slot;
+  r.work = work;
+  (void)hipEventRecord(r.a, st);
+  g_prof.push_back(r);
+  idx = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st);
 }
 
 static inline bool bad_dtype(int dtype) { return dtype != NOVA_F32 && dtype != NOVA_BF16; }
@@ -54,6 +82,27 @@ int nova_check_device(void) {
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return set_error(NOVA_ERR_DEVICE, "hipGetDeviceProperties failed");
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return set_error(NOVA_ERR_DEVICE, "device %d is %s; libnova_hip is built for gfx950 only", dev, prop.gcnArchName);
+  return 0;
+}
+
+int nova_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int nova_prof_collect(double* ms, double* work, long long* launches, int slots) {
+  NOVA_REQUIRE(ms && work && launches && slots >= PROF_SLOTS, NOVA_ERR_ARG, "prof_collect: need %d slots", PROF_SLOTS);
+  for (int i = 0; i < slots; ++i) { ms[i] = 0; work[i] = 0; launches[i] = 0; }
+  for (auto& r : g_prof) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+      ms[r.slot] += t;
+      work[r.slot] += r.work;
+      launches[r.slot] += 1;
+    }
+    g_prof_pool.emplace_back(r.a, r.b);
+  }
+  g_prof.clear();
   return 0;
 }
 

@@ -184,6 +184,7 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
     return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(ntm * ntn), block(256);
+  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
   const T* a = static_cast<const T*>(A);
   const T* w = static_cast<const T*>(W);
   T* c = static_cast<T*>(C);

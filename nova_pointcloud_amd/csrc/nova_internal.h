@@ -10,6 +10,16 @@ int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3
 // hipGetLastError() -> NOVA_ERR_LAUNCH (+ message) or 0. Never synchronises.
 int check_launch(const char* what);
 
+// ---- optional per-kernel timing with HIP events on the launch stream (capi.hip). Slots: one per
+// kernel family; `work` = algorithmic FLOPs (or bytes) of the launch. No-ops unless enabled.
+enum { PROF_GEMM_NONE = 0, PROF_GEMM_GELU, PROF_GEMM_SILU, PROF_GEMM_ROPE, PROF_ATTN, PROF_ROWNORM, PROF_SLOTS };
+struct ProfScope {
+  ProfScope(int slot, double work, hipStream_t st);
+  ~ProfScope();
+  int idx;
+  hipStream_t st;
+};
+
 // ---- gemm.hip
 int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                   int dtype, hipStream_t st);

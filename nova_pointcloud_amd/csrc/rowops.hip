@@ -96,6 +96,10 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
     return set_error(NOVA_ERR_SHAPE, "row_norm: modulation offsets must be multiples of 4");
   if ((a.gamma == nullptr) != (a.beta == nullptr)) return set_error(NOVA_ERR_ARG, "row_norm: gamma/beta must come together");
   dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
+  // algorithmic bytes: read in (+res, +mod terms) and write out once
+  const double esz = dtype == NOVA_BF16 ? 2.0 : 4.0;
+  const int nmod = a.mod ? ((a.scale_off >= 0 ? 2 : 0) + (a.gate_off >= 0 ? 1 : 0)) : 0;
+  ProfScope prof(PROF_ROWNORM, esz * a.rows * a.D * (2.0 + (a.res ? 1 : 0) + nmod), st);
   if (dtype == NOVA_BF16) hipLaunchKernelGGL(row_norm_kernel<bf16_t>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(row_norm_kernel<float>, grid, block, 0, st, a);
   return check_launch("row_norm");

@@ -1,0 +1,31 @@
+"""Access to the MI355X backend (nova_pointcloud_amd.hip / .engine) from the `diffnext` package.
+
+`diffnext` can be imported either as `nova_pointcloud_amd.diffnext` or, when
+`<repo>/nova_pointcloud_amd` is put on PYTHONPATH to shadow the reference, as top-level
+`diffnext`. In both cases the backend is the single module pair `nova_pointcloud_amd.hip` /
+`nova_pointcloud_amd.engine`; this file makes sure its parent directory is importable.
+"""
+import importlib
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def _module(name):
+    try:
+        return importlib.import_module("nova_pointcloud_amd." + name)
+    except ModuleNotFoundError as e:
+        if e.name not in ("nova_pointcloud_amd", "nova_pointcloud_amd." + name):
+            raise
+        sys.path.append(_ROOT)
+        return importlib.import_module("nova_pointcloud_amd." + name)
+
+
+def hip():
+    """ctypes binding of libnova_hip.so; loading fails loudly when the library is not built."""
+    return _module("hip")
+
+
+def engine():
+    return _module("engine")

@@ -1,0 +1,443 @@
+"""MI355X execution engine of the NOVA generation hot path.
+
+Drives libnova_hip.so (C ABI in include/nova_hip.h) for everything below
+`Transformer3DModel.forward` in eval mode (reference diffnext/models/transformers/
+transformer_3d.py:102-164,192-200): text/condition prefix, the 16-block conditioning ViT, the
+masked-autoregressive loop over the 32-block ViT (known-token gather -> first half -> scatter ->
+second half -> final LN on the rows being predicted) and the flow-matching denoise loop of the
+diffusion MLP. PyTorch supplies device memory, the current stream and a few index tensors; all
+arithmetic on activations runs in the hand-written gfx950 kernels. There is no fallback: a
+missing library or a non-gfx950 device raises `NovaHipError`.
+
+Data layout in HBM (all row-major, one token per row):
+  weights      GEMM weights in the activation dtype exactly as nn.Linear stores them ([N][K]);
+               biases / LayerNorm affines as float32; AdaLN projections of all diffusion blocks
+               concatenated to one [(3*depth+2)D, D] matrix
+  activations  x [S*L, D] residual stream (S = 2B guidance rows: cond then uncond), fused
+               qkv [S*L, 3D] read in place by attention, hidden [S*L, 4D]
+  point state  canvas [B, N, P] float32 patch vectors (P = p*p*C, = xyz for point sets),
+               mask [B, N] float32, generation order [B, N] int64
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import hip
+
+_F32 = torch.float32
+
+
+def _f32(t):
+    return t.detach().to(_F32).contiguous()
+
+
+class _Pack(object):
+    """Device-resident parameter views/copies + the ctypes structs pointing at them."""
+
+    def __init__(self):
+        self.keep = []
+
+    def w(self, t, dtype):
+        t = t.detach()
+        t = t if (t.dtype == dtype and t.is_contiguous()) else t.to(dtype).contiguous()
+        self.keep.append(t)
+        return t.data_ptr()
+
+    def f(self, t):
+        t = _f32(t)
+        self.keep.append(t)
+        return t.data_ptr()
+
+
+def pack_vit_blocks(blocks, dtype):
+    """nova_vit_block[] for a list of `Block` modules (state_dict names in include/nova_hip.h)."""
+    pk = _Pack()
+    arr = (hip.VitBlock * len(blocks))()
+    for i, b in enumerate(blocks):
+        arr[i] = hip.VitBlock(
+            pk.w(b.attn.qkv.weight, dtype), pk.f(b.attn.qkv.bias), pk.w(b.attn.proj.weight, dtype), pk.f(b.attn.proj.bias),
+            pk.f(b.norm1.weight), pk.f(b.norm1.bias), pk.w(b.mlp.fc1.weight, dtype), pk.f(b.mlp.fc1.bias),
+            pk.w(b.mlp.fc2.weight, dtype), pk.f(b.mlp.fc2.bias), pk.f(b.norm2.weight), pk.f(b.norm2.bias))
+    pk.arr = arr
+    return pk
+
+
+def patch_weight(conv):
+    """Conv2d [D, C, p, p] -> [D, p*p*C] in the patchified (row, col, channel) order."""
+    w = conv.weight.detach()
+    return w.permute(0, 2, 3, 1).reshape(w.size(0), -1).contiguous()
+
+
+def pack_decoder(dec, dtype):
+    """nova_decoder for a `DiffusionMLP` module."""
+    pk = _Pack()
+    depth = len(dec.blocks)
+    blocks = (hip.MlpBlock * depth)()
+    for i, b in enumerate(dec.blocks):
+        blocks[i] = hip.MlpBlock(pk.w(b.proj.fc1.weight, dtype), pk.f(b.proj.fc1.bias), pk.w(b.proj.fc2.weight, dtype),
+                                 pk.f(b.proj.fc2.bias), pk.f(b.norm2.weight), pk.f(b.norm2.bias))
+    adaln_w = torch.cat([b.norm1.proj.weight.detach() for b in dec.blocks] + [dec.norm.proj.weight.detach()])
+    adaln_b = torch.cat([b.norm1.proj.bias.detach() for b in dec.blocks] + [dec.norm.proj.bias.detach()])
+    pk.blocks = blocks
+    pk.struct = hip.Decoder(depth, ctypes.cast(blocks, ctypes.POINTER(hip.MlpBlock)), pk.w(adaln_w, dtype), pk.f(adaln_b),
+                            pk.w(patch_weight(dec.patch_embed.proj), dtype), pk.f(dec.patch_embed.proj.bias),
+                            pk.w(dec.head.weight, dtype), pk.f(dec.head.bias))
+    tc = dec.time_cond_embed
+    pk.time = [(pk.w(p.fc1.weight, dtype), pk.f(p.fc1.bias), pk.w(p.fc2.weight, dtype), pk.f(p.fc2.bias))
+               for p in (tc.timestep_proj, tc.condition_proj)]
+    pk.depth = depth
+    return pk
+
+
+class _Guidance(object):
+    """The guidance knobs of guidance_scaler.py:24-44 the loop needs (scale decay, truncation, renorm)."""
+
+    def __init__(self, inputs):
+        self.guidance_scale = inputs.get("guidance_scale", 1)
+        self.guidance_trunc = inputs.get("guidance_trunc", 0)
+        self.guidance_renorm = inputs.get("guidance_renorm", 1)
+        self.extra_pass = inputs.get("image_guidance_scale", 0) + inputs.get("spatiotemporal_guidance_scale", 0) > 0
+        self.min_guidance_scale = inputs.get("min_guidance_scale", None) or self.guidance_scale
+        self.inc_guidance_scale = self.guidance_scale - self.min_guidance_scale
+
+    def decay_guidance_scale(self, decay=0):
+        self.guidance_scale = self.inc_guidance_scale * decay + self.min_guidance_scale
+
+
+def _params_signature(module):
+    return tuple((p.data_ptr(), p._version, p.dtype) for p in module.parameters())
+
+
+class NovaEngine(object):
+    """Runs `Transformer3DModel` generation on one MI355X. Built lazily per model, re-packed when
+    parameters move, change dtype or are updated in place."""
+
+    def __init__(self, model):
+        hip.load()
+        self.model = model
+        self.sig = None
+        self.ws_key, self.ws = None, {}
+
+    # ------------------------------------------------------------------ packing / workspaces
+    @classmethod
+    def for_model(cls, model):
+        eng = model.__dict__.get("_nova_engine", None)
+        if eng is None:
+            eng = model.__dict__["_nova_engine"] = cls(model)
+        return eng
+
+    def _refresh(self):
+        m = self.model
+        sig = _params_signature(m)
+        if sig == self.sig:
+            return
+        dev = next(m.parameters()).device
+        dtype = next(p for p in m.parameters() if p.is_floating_point()).dtype
+        hip.dtype_code(dtype)  # raises for anything but f32 / bf16
+        self.dev, self.dtype, self.code = dev, dtype, hip.dtype_code(dtype)
+        ve, ie, de = m.video_encoder, m.image_encoder, m.image_decoder
+        self.D = ie.embed_dim
+        self.heads = ie.blocks[0].attn.num_heads
+        self.hidden = ie.blocks[0].mlp.fc1.out_features
+        self.video = pack_vit_blocks(list(ve.blocks), dtype)
+        half = ie.encoder_depth
+        self.enc1 = pack_vit_blocks(list(ie.blocks[:half]), dtype)
+        self.enc2 = pack_vit_blocks(list(ie.blocks[half:]), dtype)
+        self.dec = pack_decoder(de, dtype)
+        pk = self.misc = _Pack()
+        te = m.text_embed
+        self.text = (pk.w(te.proj.weight, dtype), pk.f(te.proj.bias), pk.f(te.norm.weight), pk.f(te.norm.bias))
+        self.vnorm = (pk.f(ve.norm.weight), pk.f(ve.norm.bias))
+        self.inorm = (pk.f(ie.norm.weight), pk.f(ie.norm.bias))
+        self.patch = (pk.w(patch_weight(ie.patch_embed.proj), dtype), pk.f(ie.patch_embed.proj.bias))
+        self.mask_token = pk.w(m.mask_embed.mask_token, dtype)
+        self.time_freq = torch.arange(128, dtype=_F32, device=dev).mul(-9.210340371976184 / 128).exp()
+        self.vtime = None
+        vpe = m.video_pos_embed
+        if hasattr(vpe, "time_proj"):  # abs-PE checkpoints: VideoPosEmbed's frame-index MLP (embeddings.py:94-111)
+            self.vtime = (pk.w(vpe.time_proj[0].weight, dtype), pk.f(vpe.time_proj[0].bias), pk.w(vpe.time_proj[2].weight, dtype),
+                          pk.f(vpe.time_proj[2].bias), pk.f(vpe.norm.weight), pk.f(vpe.norm.bias))
+        self.sig = sig
+
+    def _workspace(self, S, B, N, L, nmax):
+        key = (S, B, N, L, nmax, self.dtype, self.dev)
+        if key != self.ws_key:
+            D, dt, dev = self.D, self.dtype, self.dev
+            e = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
+            rows = S * L
+            self.ws = dict(x1=e(rows, D), x2=e(rows, D), qkv=e(rows, 3 * D), a=e(rows, D), b=e(rows, D),
+                           h=e(rows, self.hidden), z0=e(B * N, D), da=e(S * nmax, D), du=e(S * nmax, D), dh=e(S * nmax, D),
+                           df=e(S * nmax, D), dg=e(S * nmax, D), dmod=e(S * nmax, (3 * self.dec.depth + 2) * D))
+            self.ws_key = key
+        return self.ws
+
+    # ------------------------------------------------------------------ building blocks
+    def _blocks(self, pack, x, S, L, rope, rope_batch, ws):
+        hip.call("nova_vit_blocks_forward", pack.arr, len(pack.arr), x.data_ptr(), S, L, self.D, self.heads, self.hidden,
+                 hip.ptr(rope), rope_batch, ws["qkv"].data_ptr(), ws["a"].data_ptr(), ws["b"].data_ptr(),
+                 ws["h"].data_ptr(), self.code, hip.stream_ptr())
+
+    def _gemm(self, a, w_ptr, b_ptr, N, act=hip.ACT_NONE):
+        M, K = a.shape
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+        hip.call("nova_gemm_bias_act", a.data_ptr(), w_ptr, b_ptr, out.data_ptr(), M, N, K, act, self.code, hip.stream_ptr())
+        return out
+
+    def _norm_rows(self, x, gb, gather=None, rows=None, eps=1e-5):
+        rows = (gather.numel() if gather is not None else x.shape[0]) if rows is None else rows
+        out = torch.empty(rows, self.D, dtype=x.dtype, device=x.device)
+        hip.call("nova_row_norm", x.data_ptr(), out.data_ptr(), gb[0], gb[1], None, 0, -1, -1, -1, None, hip.ptr(gather),
+                 rows, self.D, eps, self.code, hip.stream_ptr())
+        return out
+
+    def _sequence(self, out, prefix, prefix_rows, tokens, tok_rows, ids, S, B, Lp, n_sel):
+        hip.call("nova_build_sequence", hip.ptr(prefix) if Lp else None, prefix_rows, hip.ptr(tokens) if n_sel else None,
+                 tok_rows, hip.ptr(ids), out.data_ptr(), S, B, Lp, n_sel, self.D, self.code, hip.stream_ptr())
+
+    def timestep_table(self, timesteps):
+        """temb[i] = timestep_proj(freq_embed(t_i)) for every diffusion step (diffusion_mlp.py:65-73)."""
+        t = torch.as_tensor(np.asarray(timesteps, dtype="float32"), device=self.dev)
+        feats = torch.empty(t.numel(), 256, dtype=self.dtype, device=self.dev)
+        hip.call("nova_timestep_freq", t.data_ptr(), self.time_freq.data_ptr(), feats.data_ptr(), t.numel(), 256, self.code,
+                 hip.stream_ptr())
+        w1, b1, w2, b2 = self.dec.time[0]
+        return self._gemm(self._gemm(feats, w1, b1, self.D, hip.ACT_SILU), w2, b2, self.D)
+
+    # ------------------------------------------------------------------ the generation loop
+    @torch.no_grad()
+    def generate(self, inputs):
+        """Eval-mode `Transformer3DModel.forward` body for max_latent_length == 1. Returns x [B,C,1,H,W]."""
+        m = self.model
+        self._refresh()
+        dev, dtype, D = self.dev, self.dtype, self.D
+        scaler = _Guidance(inputs)
+        if scaler.extra_pass:
+            raise NotImplementedError("3-pass (image / spatiotemporal) guidance is a video feature: not built on the HIP path")
+        if scaler.guidance_renorm < 1:
+            raise NotImplementedError("guidance_renorm < 1 is not built on the HIP path yet")
+        if inputs.get("max_latent_length", 1) != 1:
+            raise NotImplementedError("max_latent_length > 1 (video, KV-cached frames) is not built on the HIP path")
+        sched = m.sample_scheduler
+        if not hasattr(sched, "sigmas") or type(sched).__name__ != "FlowMatchEulerDiscreteScheduler":
+            raise NotImplementedError(f"sampler {type(sched).__name__} is not built on the HIP path (flow-matching Euler is)")
+
+        ie, ve = m.image_encoder, m.video_encoder
+        C, (H, W), p = ie.image_dim, ie.image_size, ie.patch_embed.patch_size
+        h, w = H // p, W // p
+        pv = ve.patch_embed.patch_size
+        hv, wv = H // pv, W // pv
+        N, Nv, P = h * w, hv * wv, p * p * C
+        prompt = inputs["prompt"]
+        if isinstance(prompt, (tuple, list)):  # strings or per-prompt embeddings: host-side padding (embeddings.py:179-201)
+            prompt = m.text_embed.encode_prompts(prompt)
+        S, Lt = prompt.shape[0], prompt.shape[1]
+        cfg_on = scaler.guidance_scale > 1
+        B = S // 2 if cfg_on else S
+        generator = inputs.get("generator", None)
+        host_rng = generator is not None and generator.device.type == "cpu"
+        rng_dev = "cpu" if host_rng else dev
+
+        steps = inputs.get("num_diffusion_steps", 25)
+        sched.set_timesteps(steps)
+        timesteps = np.asarray(sched.timesteps, dtype="float32")
+        sig = sched.sigmas
+        dts = (ctypes.c_float * steps)(*[sig[j + 1] - sig[j] for j in range(steps)])
+        num_preds = [int(v) for v in inputs["num_preds"] if v > 0]
+        nmax = max(num_preds) if num_preds else 1
+        L2 = Nv + N
+        latents = inputs.get("latents", [])
+        if latents:  # prefilled first frame with max_latent_length == 1: nothing to generate (transformer_3d.py:159-160)
+            return torch.stack([latents[-1].to(device=dev, dtype=dtype)], dim=2)
+        ws = self._workspace(S, B, N, max(L2, Lt + Nv), nmax)
+        code, st = self.code, hip.stream_ptr
+
+        # ---- text prefix: TextEmbed.forward (embeddings.py:203-206)
+        pr = prompt.to(device=dev, dtype=dtype).reshape(S * Lt, -1).contiguous()
+        c_txt = self._norm_rows(self._gemm(pr, self.text[0], self.text[1], D), self.text[2:])
+        temb = self.timestep_table(timesteps)
+
+        # ---- conditioning ViT over [text ; bos canvas] (transformer_3d.py:151-155)
+        vtok = m.mask_embed.bos_token.detach().to(dtype).expand(Nv, D)
+        rope_v = rope_i = pos_img = inv_freq = img_pe = None
+        hd = D // self.heads
+        if m.image_pos_embed is not None:
+            pos_v = m.video_pos_embed.get_pos(1)[0].to(device=dev, dtype=_F32).contiguous()
+            pos_img = m.image_pos_embed.get_pos(1)[0].to(device=dev, dtype=_F32).contiguous()
+            inv_freq = m.image_pos_embed.inv_freq().to(device=dev, dtype=_F32).contiguous()
+            inv_freq_v = m.video_pos_embed.inv_freq().to(device=dev, dtype=_F32).contiguous()
+            rope_v = hip.rope_table(pos_v, None, Lt, inv_freq_v, 1, hd)
+            rope_i = hip.rope_table(pos_img, None, Nv, inv_freq, 1, hd)
+        else:  # abs-PE: bos + time_embed[0] + sincos (transformer_3d.py:154, embeddings.py:113-115)
+            vpe = m.video_pos_embed
+            ang = torch.zeros(1, 1, dtype=_F32) * vpe.freq_t  # frame index 0 of T = 1 (embeddings.py:103-111)
+            feats = torch.cat([ang.sin(), ang.cos()], dim=-1).to(device=dev, dtype=dtype)
+            w1, b1, w2, b2, g, bt = self.vtime
+            t_emb = self._norm_rows(self._gemm(self._gemm(feats, w1, b1, D, hip.ACT_SILU), w2, b2, D), (g, bt))
+            vtok = vtok + t_emb + vpe.get_space_embed(dev, dtype)
+            img_pe = ie.pos_embed.get_space_embed(dev, dtype).contiguous()
+        vtok = vtok.contiguous()
+        Lv = Lt + Nv
+        xv = ws["x1"][: S * Lv]
+        self._sequence(xv, c_txt, Lt, vtok, 0, None, S, B, Lt, Nv)
+        self._blocks(self.video, xv, S, Lv, rope_v, 1, ws)
+        ar = torch.arange(S, device=dev, dtype=torch.int32)
+        vrows = (ar[:, None] * Lv + Lt + torch.arange(Nv, device=dev, dtype=torch.int32)[None]).reshape(-1).contiguous()
+        c = self._norm_rows(xv, self.vnorm, gather=vrows)  # [S*Nv, D]
+
+        # ---- masked autoregressive loop (transformer_3d.py:115-133)
+        canvas = torch.zeros(B, N, P, dtype=_F32, device=dev)
+        mask = torch.ones(B, N, dtype=_F32, device=dev)
+        order = inputs.get("pred_order", None)  # test hook: inject the generation order [B, N]
+        if order is None:
+            u = torch.empty(B, N, 1, dtype=_F32, device=rng_dev).uniform_(generator=generator)
+            order = u.argsort(dim=1)[..., 0]
+        order = order.to(dev).contiguous()
+        m.mask_embed.pred_ids = order.unsqueeze(-1)
+        noise_fn = inputs.get("noise_fn", None)  # test hook: replay recorded per-step noise
+        noise = torch.empty(B, C, H, W, dtype=_F32, device=rng_dev)
+        srow = (torch.arange(S, device=dev, dtype=torch.int64) * L2 + Nv)[:, None]
+        done = 0
+        for i, n in enumerate(num_preds):
+            scaler.decay_guidance_scale((i + 1) / len(num_preds))
+            if cfg_on and scaler.guidance_scale <= 1:
+                raise NotImplementedError("guidance decaying to <= 1 inside a CFG run is undefined in the reference")
+            g_step = (ctypes.c_float * steps)(*[
+                1.0 if (cfg_on and scaler.guidance_trunc and float(t) < scaler.guidance_trunc) else float(scaler.guidance_scale)
+                for t in timesteps])
+            z0 = ws["z0"]
+            hip.call("nova_embed_canvas", canvas.data_ptr(), mask.data_ptr(), self.patch[0], self.patch[1], self.mask_token,
+                     hip.ptr(img_pe), z0.data_ptr(), B, N, P, D, code, st())
+            prev_ids = order[:, :done].contiguous()
+            pred_ids = order[:, done : done + n].contiguous()
+            mask.scatter_(1, pred_ids, 0.0)
+            # first half: [c ; known tokens in generation order]
+            L1 = Nv + done
+            x1 = ws["x1"][: S * L1]
+            self._sequence(x1, c, Nv, z0, N, prev_ids if done else None, S, B, Nv, done)
+            rope1 = hip.rope_table(pos_img, prev_ids, Nv, inv_freq, B, hd) if (pos_img is not None and done) else (
+                rope_i[:, :Nv].contiguous() if pos_img is not None else None)
+            self._blocks(self.enc1, x1, S, L1, rope1, B if (pos_img is not None and done) else 1, ws)
+            # second half: [c' ; full canvas with the known tokens scattered back]
+            x2 = ws["x2"][: S * L2]
+            self._sequence(x2, x1, L1, z0, N, None, S, B, Nv, N)
+            if done:
+                hip.call("nova_scatter_tokens", x1.data_ptr(), prev_ids.data_ptr(), x2.data_ptr(), S, B, Nv, N, done, D, code, st())
+            self._blocks(self.enc2, x2, S, L2, rope_i, 1, ws)
+            # final LN only on the rows predicted now, then the condition projection (time term added per step)
+            rows = (srow + torch.cat([pred_ids] * (S // B))).to(torch.int32).reshape(-1).contiguous()
+            zc = self._norm_rows(x2, self.inorm, gather=rows)
+            w1, b1, w2, b2 = self.dec.time[1]
+            zc = self._gemm(self._gemm(zc, w1, b1, D, hip.ACT_SILU), w2, b2, D)
+            # noise for this step (RNG contract: one normal_ [B,C,H,W] per AR step, transformer_3d.py:131)
+            if noise_fn is not None:
+                noise = noise_fn(i).to(_F32)
+            else:
+                noise.normal_(generator=generator)
+            nz = noise.to(dev).reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P)
+            x_n = nz.gather(1, pred_ids[..., None].expand(-1, -1, P)).contiguous()
+            hip.call("nova_decoder_denoise", ctypes.byref(self.dec.struct), zc.data_ptr(), temb.data_ptr(), x_n.data_ptr(), dts,
+                     g_step, steps, S, B, n, P, D, ws["da"].data_ptr(), ws["du"].data_ptr(), ws["dh"].data_ptr(),
+                     ws["df"].data_ptr(), ws["dg"].data_ptr(), ws["dmod"].data_ptr(), code, st())
+            canvas.scatter_(1, pred_ids[..., None].expand(-1, -1, P), x_n)
+            done += n
+        m.mask_embed.mask, m.mask_embed.pred_pos = mask.unsqueeze(-1).to(dtype), done
+        x = canvas.reshape(B, h, w, p, p, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, H, W)
+        return x.to(dtype).unsqueeze(2)
+
+
+# --------------------------------------------------------------------------------------------
+# module-level entry points (what `Block.forward`, `VisionTransformer.forward` and
+# `DiffusionMLP.forward` of the drop-in package call for device tensors without autograd)
+# --------------------------------------------------------------------------------------------
+def _cached_pack(owner, key, build):
+    sig = (key, _params_signature(owner))
+    cache = owner.__dict__.setdefault("_nova_packs", {})
+    if cache.get("sig") != sig:
+        cache.clear()
+        cache.update(sig=sig, pack=build())
+    return cache["pack"]
+
+
+def block_stack_forward(blocks, x, pe_func=None):
+    """Run a list of `Block` modules on x [S, L, D] through nova_vit_blocks_forward (returns a new tensor)."""
+    hip.load()
+    S, L, D = x.shape
+    first = blocks[0]
+    pack = _cached_pack(first, ("vit", len(blocks), tuple(id(b) for b in blocks), x.dtype),
+                        lambda: pack_vit_blocks(blocks, x.dtype))
+    heads, hidden = first.attn.num_heads, first.mlp.fc1.out_features
+    rope = None
+    if pe_func is not None:
+        w = pe_func.weight[:, 0]
+        rope = torch.stack([w[..., 0, 0], w[..., 1, 0]], dim=-1).float().contiguous()
+    rows = S * L
+    out = x.reshape(rows, D).clone()
+    e = lambda n: torch.empty(rows, n, dtype=x.dtype, device=x.device)
+    qkv, a, b, h = e(3 * D), e(D), e(D), e(hidden)
+    hip.call("nova_vit_blocks_forward", pack.arr, len(pack.arr), out.data_ptr(), S, L, D, heads, hidden, hip.ptr(rope),
+             rope.shape[0] if rope is not None else 1, qkv.data_ptr(), a.data_ptr(), b.data_ptr(), h.data_ptr(),
+             hip.dtype_code(x.dtype), hip.stream_ptr())
+    return out.view(S, L, D)
+
+
+def decoder_forward(dec, x_img, timestep, z, pred_ids=None):
+    """`DiffusionMLP.forward` (diffusion_mlp.py:89-99) for device tensors: one velocity prediction."""
+    hip.load()
+    dtype, dev = z.dtype, z.device
+    code, st = hip.dtype_code(dtype), hip.stream_ptr
+    pk = _cached_pack(dec, ("dec", dtype), lambda: pack_decoder(dec, dtype))
+    pe = dec.patch_embed
+    S, D = z.shape[0], z.shape[-1]
+    if x_img.dim() != 4:
+        raise NotImplementedError("decoder_forward expects the noisy canvas as [S, C, H, W]")
+    pe.height, pe.width = x_img.size(-2) // pe.patch_size, x_img.size(-1) // pe.patch_size
+    echo = pe.patchify(x_img)
+    N, P = echo.shape[1], echo.shape[2]
+    ids = pred_ids[..., 0] if pred_ids is not None else torch.arange(N, device=dev).expand(S, -1)
+    n = ids.shape[1]
+    x_rows = echo.float().gather(1, ids[..., None].expand(-1, -1, P)).contiguous()  # [S, n, P] f32
+    rows = (torch.arange(S, device=dev)[:, None] * z.shape[1] + ids).to(torch.int32).reshape(-1).contiguous()
+    zf = z.reshape(-1, D).contiguous()
+    zg = torch.empty(S * n, D, dtype=dtype, device=dev)
+    hip.call("nova_build_sequence", None, 0, zf.data_ptr(), z.shape[1], ids.contiguous().data_ptr(), zg.data_ptr(), S, S, 0, n, D,
+             code, st())
+    gemm = lambda a, w, b, N_, act=hip.ACT_NONE: _gemm_ptr(a, w, b, N_, act, code)
+    w1, b1, w2, b2 = pk.time[1]
+    cond = gemm(gemm(zg, w1, b1, D, hip.ACT_SILU), w2, b2, D)
+    # timestep features -> timestep_proj, one row per sequence
+    t = torch.as_tensor(timestep, device=dev).float().reshape(-1).expand(S).contiguous()
+    freq = torch.arange(128, dtype=_F32, device=dev).mul(-9.210340371976184 / 128).exp()
+    feats = torch.empty(S, 256, dtype=dtype, device=dev)
+    hip.call("nova_timestep_freq", t.data_ptr(), freq.data_ptr(), feats.data_ptr(), S, 256, code, st())
+    w1, b1, w2, b2 = pk.time[0]
+    temb = gemm(gemm(feats, w1, b1, D, hip.ACT_SILU), w2, b2, D)
+    es = zg.element_size()
+    act = torch.empty_like(cond)
+    for s in range(S):  # SiLU(cond + temb[s]) per sequence (timesteps may differ per sequence)
+        hip.call("nova_silu_add_rows", cond.data_ptr() + s * n * D * es, temb.data_ptr() + s * D * es,
+                 act.data_ptr() + s * n * D * es, n, D, code, st())
+    depth = pk.depth
+    mod = gemm(act, pk.struct.adaln_w, pk.struct.adaln_b, (3 * depth + 2) * D)
+    u = torch.empty(S * n, D, dtype=dtype, device=dev)
+    hip.call("nova_patch_embed_rows", x_rows.data_ptr(), pk.struct.patch_w, pk.struct.patch_b, u.data_ptr(), S, S, n, P, D,
+             code, st())
+    for i in range(depth):
+        blk = pk.blocks[i]
+        h = hip.row_norm(u, mod=mod, scale_off=i * 3 * D, shift_off=i * 3 * D + D, eps=1e-6)
+        g = gemm(gemm(h, blk.fc1_w, blk.fc1_b, D, hip.ACT_SILU), blk.fc2_w, blk.fc2_b, D)
+        hip.call("nova_row_norm", g.data_ptr(), u.data_ptr(), blk.norm2_w, blk.norm2_b, mod.data_ptr(), mod.shape[1], -1, -1,
+                 i * 3 * D + 2 * D, u.data_ptr(), None, S * n, D, 1e-5, code, st())
+    h = hip.row_norm(u, mod=mod, scale_off=depth * 3 * D, shift_off=depth * 3 * D + D, eps=1e-6)
+    pred = torch.zeros(S, n, P, dtype=_F32, device=dev)
+    hip.call("nova_head_cfg_euler", h.data_ptr(), pk.struct.head_w, pk.struct.head_b, pred.data_ptr(), S, n, P, D, 1.0, 0, 1.0,
+             code, st())
+    pred = pred.to(dtype)
+    return pred if pred_ids is None else echo.scatter(1, ids[..., None].expand(-1, -1, P), pred)
+
+
+def _gemm_ptr(a, w_ptr, b_ptr, N, act, code):
+    M, K = a.shape
+    out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    hip.call("nova_gemm_bias_act", a.data_ptr(), w_ptr, b_ptr, out.data_ptr(), M, N, K, act, code, hip.stream_ptr())
+    return out

@@ -67,6 +67,10 @@ SIGNATURES = {
     "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_float),
                              ctypes.POINTER(c_float)] + [c_int] * 6 + [c_void_p] * 6 + [c_int, c_void_p],
 }
+SIGNATURES["nova_prof_enable"] = [c_int]
+SIGNATURES["nova_prof_collect"] = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                   ctypes.POINTER(ctypes.c_longlong), c_int]
+PROF_SLOTS = ["gemm_bias", "gemm_bias_gelu", "gemm_bias_silu", "qkv_gemm_rope", "attention", "row_norm"]
 PLAIN = {"nova_version": (c_int, []), "nova_last_error": (ctypes.c_char_p, []), "nova_check_device": (c_int, [])}
 
 
@@ -197,3 +201,15 @@ def row_norm(x, out=None, gamma=None, beta=None, mod=None, scale_off=-1, shift_o
          scale_off, shift_off, gate_off, ptr(res), ptr(gather, torch.int32), rows, D, float(eps),
          dtype_code(x.dtype), stream_ptr())
     return out
+
+
+def prof_enable(on=True):
+    call("nova_prof_enable", 1 if on else 0)
+
+
+def prof_collect():
+    """{slot name: (milliseconds, algorithmic work, launches)} since the last collect; waits for the events."""
+    n = len(PROF_SLOTS)
+    ms, work, cnt = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_longlong * n)()
+    call("nova_prof_collect", ms, work, cnt, n)
+    return {PROF_SLOTS[i]: (ms[i], work[i], cnt[i]) for i in range(n)}

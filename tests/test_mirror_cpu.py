@@ -1,0 +1,133 @@
+"""CPU: the drop-in `diffnext` package (PyTorch definitions + host logic of the pipeline) against
+the golden vectors of the reference, and its API surface (names, kwargs, state_dict schema)."""
+import inspect
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, Golden
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nova_pointcloud_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)  # how a user shadows the reference's `diffnext`
+
+from diffnext.models.transformers import transformer_nova as TN  # noqa: E402
+from diffnext.pipelines import NOVAPipeline  # noqa: E402
+from diffnext.pipelines.nova.pipeline_nova import cosine_set_sizes, points_from_latents  # noqa: E402
+from diffnext.schedulers import DDPMScheduler, FlowMatchEulerDiscreteScheduler  # noqa: E402
+
+
+def build_from_golden(g, dtype=torch.float32, device="cpu"):
+    """NOVATransformer3DModel with the fixture's tiny architecture, weights loaded strictly."""
+    m = g.meta
+    D, heads = m["D"], m["heads"]
+    TN.VIDEO_ENCODERS.register(f"vit_d{m['video_depth']}w{D}", TN._vit, depth=m["video_depth"], embed_dim=D, num_heads=heads)
+    TN.IMAGE_ENCODERS.register(f"vit_d{m['image_depth']}w{D}", TN._vit, depth=m["image_depth"], embed_dim=D, num_heads=heads)
+    TN.IMAGE_DECODERS.register(f"mlp_d{m['decoder_depth']}w{D}", TN._mlp, depth=m["decoder_depth"], embed_dim=D)
+    stride = 16 // m["patch"]  # patch = 15 // stride + 1
+    H, W = m["latent_h"], m["latent_w"]
+    base = [H // m["patch"], W // m["patch"]]
+    model = TN.NOVATransformer3DModel(
+        image_dim=m["image_dim"], image_size=(H * stride, W * stride), image_stride=stride, text_token_dim=m["token_dim"],
+        text_token_len=m["token_len"], image_base_size=base, video_base_size=[1, base[0] // 2, base[1] // 2],
+        rotary_pos_embed=bool(m["rotary"]),
+        arch=(f"vit_d{m['video_depth']}w{D}", f"vit_d{m['image_depth']}w{D}", f"mlp_d{m['decoder_depth']}w{D}"))
+    missing = model.load_state_dict(g.weights, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.to(device=device, dtype=dtype).eval()
+
+
+@pytest.fixture(scope="module", params=CASES)
+def gold(request):
+    return Golden(request.param)
+
+
+def test_state_dict_schema_matches_reference(gold):
+    """Same parameter / persistent-buffer names and shapes as the reference's modules produced."""
+    model = build_from_golden(gold)
+    sd = model.state_dict()
+    assert set(sd) == set(gold.weights)
+    assert all(tuple(sd[k].shape) == tuple(gold.weights[k].shape) for k in sd)
+
+
+def test_pipeline_cpu_matches_reference(gold):
+    """NOVAPipeline.__call__ on CPU from the same seed reproduces the reference's latent bit-for-bit-ish."""
+    m = gold.meta
+    pipe = NOVAPipeline(transformer=build_from_golden(gold), scheduler=FlowMatchEulerDiscreteScheduler())
+    out = pipe(prompt_embeds=gold.prompt_embeds, num_inference_steps=m["K"], num_diffusion_steps=m["S"],
+               guidance_scale=m["guidance"], generator=torch.Generator().manual_seed(m["sample_seed"]),
+               output_type="latent", disable_progress_bar=True)
+    x, ref = out.frames, gold.t["out/x"]
+    assert "frames" in out and out["frames"] is x and x.shape == ref.shape
+    assert (x - ref).abs().max() <= 1e-5 * ref.abs().max()
+    assert torch.equal(pipe.transformer.mask_embed.pred_ids, gold.t["out/order"])
+    pts = points_from_latents(x)
+    assert pts.shape == (m["B"], m["latent_h"] * m["latent_w"], 3)
+
+
+def test_call_signature_matches_reference():
+    """Keyword set and defaults of NOVAPipeline.__call__ (reference pipeline_nova.py:55-78)."""
+    sig = inspect.signature(NOVAPipeline.__call__)
+    want = dict(prompt=None, num_inference_steps=64, num_diffusion_steps=25, max_latent_length=1, guidance_scale=5,
+                guidance_trunc=0, guidance_renorm=1, image_guidance_scale=0, spatiotemporal_guidance_scale=0,
+                flow_shift=None, motion_flow=5, negative_prompt=None, image=None, num_images_per_prompt=1,
+                generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None,
+                disable_progress_bar=False, output_type="pil")
+    got = {k: v.default for k, v in sig.parameters.items() if k not in ("self", "kwargs")}
+    assert got == want
+    init = inspect.signature(NOVAPipeline.__init__)
+    assert list(init.parameters)[1:] == ["transformer", "scheduler", "vae", "text_encoder", "tokenizer", "trust_remote_code"]
+
+
+def test_registry_names_and_errors():
+    for w, h in ((768, 12), (1024, 16), (1536, 16)):
+        assert TN.VIDEO_ENCODERS.has(f"vit_d16w{w}") and TN.IMAGE_ENCODERS.has(f"vit_d32w{w}") and TN.IMAGE_DECODERS.has(f"mlp_d6w{w}")
+    assert TN.IMAGE_DECODERS.has("mlp_d3w1280")
+    with pytest.raises(KeyError):
+        TN.IMAGE_ENCODERS.get("vit_d32w999")
+
+
+def test_schedule_and_sampler_grid():
+    assert cosine_set_sizes(256, 4).tolist() == [19, 56, 83, 98]
+    s = FlowMatchEulerDiscreteScheduler()
+    s.set_timesteps(25)
+    assert len(s.timesteps) == 25 and len(s.sigmas) == 26 and s.sigmas[-1] == 0
+    x, v = torch.ones(2, 3), torch.full((2, 3), 2.0)
+    s._step_index = None
+    out = s.step(v, s.timesteps[0], x).prev_sample
+    assert torch.allclose(out, x + (s.sigmas[1] - s.sigmas[0]) * v)
+    s2 = FlowMatchEulerDiscreteScheduler(shift=3.0)
+    s2.set_timesteps(8)
+    assert all(a > b for a, b in zip(s2.sigmas[:-1], s2.sigmas[1:]))
+
+
+def test_ddpm_scheduler_steps():
+    s = DDPMScheduler(num_train_timesteps=100, clip_sample=False)
+    s.set_timesteps(10)
+    assert s.timesteps.tolist() == list(range(90, -1, -10))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 4, 4, generator=g)
+    for t in s.timesteps:
+        x = s.step(torch.zeros_like(x), t, x, generator=g).prev_sample
+    assert torch.isfinite(x).all()
+
+
+def test_save_and_load_roundtrip(gold, tmp_path):
+    model = build_from_golden(gold)
+    pipe = NOVAPipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler(shift=2.0))
+    pipe.save_pretrained(str(tmp_path))
+    again = NOVAPipeline.from_pretrained(str(tmp_path))
+    assert again.scheduler.config.shift == 2.0
+    for (k, a), (_, b) in zip(model.state_dict().items(), again.transformer.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_guidance_le_one_runs_single_pass(gold):
+    m = gold.meta
+    pipe = NOVAPipeline(transformer=build_from_golden(gold), scheduler=FlowMatchEulerDiscreteScheduler())
+    out = pipe(prompt_embeds=gold.prompt_embeds, num_inference_steps=2, num_diffusion_steps=2, guidance_scale=1,
+               generator=torch.Generator().manual_seed(0), output_type="latent", disable_progress_bar=True)
+    assert out.frames.shape[0] == m["B"] and torch.isfinite(out.frames).all()

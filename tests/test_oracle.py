@@ -1,0 +1,80 @@
+"""CPU: the oracle (oracle/nova_oracle.py) against the golden vectors produced by the reference's
+own modules, plus hand-derived pins for the pieces restated from source text only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import CASES, Golden
+from oracle import nova_oracle as O
+
+
+@pytest.fixture(scope="module", params=CASES)
+def gold(request):
+    return Golden(request.param)
+
+
+def test_schedule_known_values():
+    # values obtained with the reference pipeline; sum always = N
+    assert O.cosine_schedule(256, 4).tolist() == [19, 56, 83, 98]
+    s = O.cosine_schedule(2048, 64)
+    assert s.sum() == 2048 and len(s) == 64 and s.min() >= 1 and s.max() == 51
+    s = O.cosine_schedule(256, 64)
+    assert s.sum() == 256 and (s > 0).sum() == 61
+
+
+def test_cfm_sigmas_shape_and_ends():
+    t, sig = O.cfm_sigmas(25)
+    assert len(t) == 25 and len(sig) == 26 and sig[-1] == 0
+    assert abs(sig[0] - 1.0) < 1e-7 and abs(sig[24] - 0.001) < 1e-7
+    assert t.dtype == np.float32 and abs(float(t[0]) - 1000.0) < 1e-3
+    t3, sig3 = O.cfm_sigmas(8, shift=3.0)
+    assert all(a > b for a, b in zip(sig3[:-1], sig3[1:]))
+
+
+def test_golden_schedule_matches(gold):
+    m = gold.meta
+    N = (m["latent_h"] // m["patch"]) * (m["latent_w"] // m["patch"])
+    assert O.cosine_schedule(N, m["K"]).tolist() == gold.t["in/num_preds"].tolist()
+
+
+def test_prompt_encoding_matches_reference(gold):
+    got = O.encode_prompt_embeds(gold.weights["text_embed.weight"], gold.prompt_embeds, gold.meta["token_len"])
+    assert torch.equal(got, gold.t["in/prompt"])
+
+
+def test_decoder_call_matches_reference(gold):
+    """One DiffusionMLP.forward(x, t, z, pred_ids) captured inside the reference's denoise loop."""
+    m = gold.meta
+    out = O.diffusion_mlp(gold.weights, "image_decoder.", m["decoder_depth"], gold.t["dec/x"], gold.t["dec/t"],
+                          gold.t["dec/z"], gold.t["dec/pred_ids"], m["patch"])
+    ref = gold.t["dec/out"]
+    assert (out - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def _run(gold, dtype=torch.float32, replay=False):
+    m, trace = gold.meta, {}
+    kw = dict(u_dist=gold.t["in/u_dist"], noises=list(gold.t["in/noises"])) if replay else dict(
+        generator=torch.Generator().manual_seed(m["sample_seed"]))
+    x = O.generate(gold.weights, gold.oracle_config(), gold.t["in/prompt"], gold.t["in/num_preds"].numpy(),
+                   num_diffusion_steps=m["S"], guidance_scale=m["guidance"], dtype=dtype, trace=trace, **kw)
+    return x, trace
+
+
+def test_generate_matches_reference_f32(gold):
+    """End to end from the same seed: the oracle must consume the generator exactly like the reference."""
+    x, trace = _run(gold)
+    ref = gold.t["out/x"]
+    assert torch.equal(trace["order"], gold.t["out/order"])
+    scale = ref.abs().max()
+    assert (trace["c"] - gold.t["out/c"]).abs().max() <= 1e-5 * gold.t["out/c"].abs().max()
+    assert (trace["z"][0] - gold.t["out/z_first"]).abs().max() <= 1e-5 * gold.t["out/z_first"].abs().max()
+    assert (trace["z"][-1] - gold.t["out/z_last"]).abs().max() <= 2e-5 * gold.t["out/z_last"].abs().max()
+    assert x.shape == ref.shape
+    assert (x - ref).abs().max() <= 1e-5 * scale, f"max rel err {((x - ref).abs().max() / scale).item():.3e}"
+
+
+def test_generate_f64_replay_close_to_reference(gold):
+    """float64 oracle on the replayed noise: bounds the f32 rounding of the reference itself (SURVEY: ~2e-6)."""
+    x, _ = _run(gold, torch.float64, replay=True)
+    ref = gold.t["out/x"].double()
+    assert (x - ref).abs().max() <= 5e-5 * ref.abs().max()
