@@ -136,6 +136,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from nova_pointcloud_amd import hip
+    from nova_pointcloud_amd.sharding import gather_points
     from diffnext.pipelines.nova.pipeline_nova import cosine_set_sizes, points_from_latents
 
     width, heads, H, W, B = WORKLOADS[args.workload]
@@ -145,16 +146,13 @@ def main():
     prompts = synthetic_prompts(B, device, dtype, seed=1234 + rank)  # every rank generates its own shard
     gen = torch.Generator(device=device).manual_seed(rank)
     N, Nv = H * W, (H // 2) * (W // 2)
-    gathered = torch.empty(world * B, N, 3, dtype=torch.float32, device=device) if world > 1 else None
 
     def step():
         out = pipe(prompt_embeds=prompts, num_inference_steps=args.ar_steps, num_diffusion_steps=args.diffusion_steps,
                    guidance_scale=5, generator=gen, output_type="latent", disable_progress_bar=True)
         pts = points_from_latents(out.frames).float().contiguous()  # [B, N, 3]
-        if world > 1:  # the path's only exchange: gather the generated point sets of all shards (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered, pts)
-            return gathered
-        return pts
+        # the path's only exchange: gather the generated point sets of all shards (RCCL over xGMI; no-op at N = 1)
+        return gather_points(pts)
 
     def fence():
         if world > 1:

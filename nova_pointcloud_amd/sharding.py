@@ -1,0 +1,47 @@
+"""Batch sharding of the generation path over the GPUs of a node.
+
+Samples are independent (no cross-sample op anywhere in the path), so the path shards by batch row:
+rank r generates a contiguous block of the prompts with replicated weights, and the only exchange
+is one all-gather of the generated point sets ([B_loc, N, 3] f32 per rank) — RCCL over xGMI on
+GPUs (`backend="nccl"`), gloo in the CPU tests. Each rank's call is an ordinary pipeline call, so
+per-shard parity with the reference is the single-process parity.
+"""
+import torch
+
+
+def shard_range(total, rank, world):
+    """Contiguous block [lo, hi) of `total` items owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_list(items, rank, world):
+    lo, hi = shard_range(len(items), rank, world)
+    return list(items[lo:hi])
+
+
+def gather_points(points, group=None):
+    """All-gather [B_loc, N, 3] point sets of every rank into [sum B_loc, N, 3] (rank order).
+
+    Equal shard sizes use one `all_gather_into_tensor`; ragged shards are padded to the largest.
+    """
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return points
+    world = dist.get_world_size(group)
+    points = points.contiguous()
+    sizes = torch.tensor([points.shape[0]], dtype=torch.int64, device=points.device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    counts = [int(s.item()) for s in all_sizes]
+    if len(set(counts)) == 1:
+        out = points.new_empty((world * counts[0],) + tuple(points.shape[1:]))
+        dist.all_gather_into_tensor(out, points, group=group)
+        return out
+    pad = points.new_zeros((max(counts),) + tuple(points.shape[1:]))
+    pad[: points.shape[0]] = points
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:n] for p, n in zip(parts, counts)])
