@@ -115,10 +115,18 @@ __global__ __launch_bounds__(256) void attn_bf16_hd64(const bf16_t* __restrict__
 #pragma unroll
     for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    // deferred rescale: the running max (and with it O, l) is only moved when some query of the wave saw its
+    // max grow by more than 2^8 in the exp2 domain; until then p <= 2^8, exact in f32 accumulation and with
+    // unchanged relative precision in bf16. The decision is wave-uniform; both lanes of a query agree on m.
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
+    if (__any((m_new - m_run) * c > 8.0f)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+    }
+    const float mc = m_run * c;
     float psum = 0.f;
     bf8v pb[2][2];
 #pragma unroll
@@ -131,9 +139,7 @@ __global__ __launch_bounds__(256) void attn_bf16_hd64(const bf16_t* __restrict__
           psum += p;
           pb[kb][s2][j] = (__bf16)p;
         }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+    l_run += psum;
 
     // ---- O^T[dv][q] += V^T[dv][key] P^T[key][q]
 #pragma unroll

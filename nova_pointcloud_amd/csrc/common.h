@@ -47,6 +47,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
+// exact-erf GELU to ~1.5e-7 absolute (Abramowitz-Stegun 7.1.26): 1 rcp + 1 exp2 + 7 FMA-class ops instead
+// of libm erff's ~30; used where the result is rounded to bf16 anyway (bf16 eps = 3.9e-3).
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);  // 1 - erf(z)
+  const float half_x = 0.5f * x;
+  return x >= 0.f ? fmaf(-half_x, e, x) : half_x * e;  // 0.5x(1 + erf) = x - 0.5x e ; 0.5x(1 - erf(|.|)) = 0.5x e
+}
+
 // XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a
 // contiguous chunk of the logical tile list, so neighbouring tiles hit the same per-XCD L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
       }
       if (EPI == EPI_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
       } else if (EPI == EPI_SILU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);

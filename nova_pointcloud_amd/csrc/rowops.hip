@@ -36,72 +36,124 @@ template <> struct Vec4<bf16_t> {
   }
 };
 
-constexpr int RN_MAXIT = 8;  // 8 x 256 = up to D = 2048 per row held in registers
+// One wave per row, 16-byte accesses (8 bf16 / 4 f32 per lane per chunk), the whole row (D <= 2048) held in
+// registers; the residual / modulation rows are requested together with the input row so that all of a row's
+// HBM traffic is in flight before the two wave reductions.
+template <typename T> struct Chunk;  // 16 bytes of a row as float values
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  f4v v[1];
+  static __device__ __forceinline__ Chunk load(const float* p) { Chunk c; c.v[0] = *reinterpret_cast<const f4v*>(p); return c; }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f4v*>(p) = v[0]; }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  f4v v[2];
+  static __device__ __forceinline__ Chunk load(const bf16_t* p) {
+    const u4v u = *reinterpret_cast<const u4v*>(p);
+    Chunk c;
+    c.v[0] = f4v{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+    c.v[1] = f4v{__uint_as_float(u[2] << 16), __uint_as_float(u[2] & 0xffff0000u), __uint_as_float(u[3] << 16), __uint_as_float(u[3] & 0xffff0000u)};
+    return c;
+  }
+  __device__ __forceinline__ void store(bf16_t* p) const {
+    u4v u = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]), pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
+    *reinterpret_cast<u4v*>(p) = u;
+  }
+};
 
-template <typename T>
+template <typename T, int NIT, bool HAS_RES, bool HAS_MOD>
 __global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
+  using C = Chunk<T>;
+  constexpr int NV = C::N / 4;
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const long src = a.gather ? (long)a.gather[row] : row;
   const T* in = static_cast<const T*>(a.in) + src * a.D;
-  f4v x[RN_MAXIT];
-  float sum = 0.f;
+  const T* mod = HAS_MOD ? static_cast<const T*>(a.mod) + row * a.mod_ld : nullptr;
+  const T* res = HAS_RES ? static_cast<const T*>(a.res) + row * a.D : nullptr;
+  const bool has_ss = HAS_MOD && a.scale_off >= 0, has_gate = HAS_MOD && a.gate_off >= 0;
+  C x[NIT], r[HAS_RES ? NIT : 1], ms[HAS_MOD ? NIT : 1], mb[HAS_MOD ? NIT : 1], mg[HAS_MOD ? NIT : 1];
 #pragma unroll
-  for (int it = 0; it < RN_MAXIT; ++it) {
-    const int d = (it * 64 + lane) * 4;
+  for (int it = 0; it < NIT; ++it) {
+    const int d = (it * 64 + lane) * C::N;
     if (d < a.D) {
-      x[it] = Vec4<T>::load(in + d);
-      sum += (x[it][0] + x[it][1]) + (x[it][2] + x[it][3]);
+      x[it] = C::load(in + d);
+      if (HAS_RES) r[it] = C::load(res + d);
+      if (has_ss) { ms[it] = C::load(mod + a.scale_off + d); mb[it] = C::load(mod + a.shift_off + d); }
+      if (has_gate) mg[it] = C::load(mod + a.gate_off + d);
     }
   }
+  float sum = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+    if ((it * 64 + lane) * C::N < a.D)
+#pragma unroll
+      for (int k = 0; k < NV; ++k) sum += (x[it].v[k][0] + x[it].v[k][1]) + (x[it].v[k][2] + x[it].v[k][3]);
   const float mean = wave_sum(sum) / (float)a.D;
   float sq = 0.f;
 #pragma unroll
-  for (int it = 0; it < RN_MAXIT; ++it) {
-    const int d = (it * 64 + lane) * 4;
-    if (d < a.D) {
+  for (int it = 0; it < NIT; ++it)
+    if ((it * 64 + lane) * C::N < a.D)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float c = x[it][j] - mean;
-        sq += c * c;
-      }
-    }
-  }
+      for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float c = x[it].v[k][j] - mean;
+          sq += c * c;
+        }
   const float rstd = rsqrtf(wave_sum(sq) / (float)a.D + a.eps);
-  const T* mod = a.mod ? static_cast<const T*>(a.mod) + row * a.mod_ld : nullptr;
-  const T* res = a.res ? static_cast<const T*>(a.res) + row * a.D : nullptr;
   T* out = static_cast<T*>(a.out) + row * a.D;
 #pragma unroll
-  for (int it = 0; it < RN_MAXIT; ++it) {
-    const int d = (it * 64 + lane) * 4;
+  for (int it = 0; it < NIT; ++it) {
+    const int d = (it * 64 + lane) * C::N;
     if (d < a.D) {
-      f4v y = (x[it] - mean) * rstd;
-      if (a.gamma) y = y * *reinterpret_cast<const f4v*>(a.gamma + d) + *reinterpret_cast<const f4v*>(a.beta + d);
-      if (mod) {
-        if (a.scale_off >= 0) y = y * (1.0f + Vec4<T>::load(mod + a.scale_off + d)) + Vec4<T>::load(mod + a.shift_off + d);
-        if (a.gate_off >= 0) y = y * Vec4<T>::load(mod + a.gate_off + d);
+      C y;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        f4v v = (x[it].v[k] - mean) * rstd;
+        if (a.gamma) v = v * *reinterpret_cast<const f4v*>(a.gamma + d + 4 * k) + *reinterpret_cast<const f4v*>(a.beta + d + 4 * k);
+        if (has_ss) v = v * (1.0f + ms[it].v[k]) + mb[it].v[k];
+        if (has_gate) v = v * mg[it].v[k];
+        if (HAS_RES) v = v + r[it].v[k];
+        y.v[k] = v;
       }
-      if (res) y = y + Vec4<T>::load(res + d);
-      Vec4<T>::store(out + d, y);
+      y.store(out + d);
     }
   }
 }
 
+template <typename T, int NIT>
+static void launch_row_norm(const RowNormArgs& a, dim3 grid, hipStream_t st) {
+  const bool r = a.res != nullptr, m = a.mod != nullptr;
+  if (r && m) hipLaunchKernelGGL((row_norm_kernel<T, NIT, true, true>), grid, dim3(256), 0, st, a);
+  else if (r) hipLaunchKernelGGL((row_norm_kernel<T, NIT, true, false>), grid, dim3(256), 0, st, a);
+  else if (m) hipLaunchKernelGGL((row_norm_kernel<T, NIT, false, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((row_norm_kernel<T, NIT, false, false>), grid, dim3(256), 0, st, a);
+}
+
 int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
   if (a.rows <= 0) return 0;
-  if (a.D % 4 != 0 || a.D > RN_MAXIT * 256) return set_error(NOVA_ERR_SHAPE, "row_norm: D=%d unsupported (need D %% 4 == 0, D <= 2048)", a.D);
-  if (a.mod && (a.mod_ld % 4 || (a.scale_off >= 0 && (a.scale_off % 4 || a.shift_off % 4 || a.shift_off < 0)) ||
-                (a.gate_off >= 0 && a.gate_off % 4)))
-    return set_error(NOVA_ERR_SHAPE, "row_norm: modulation offsets must be multiples of 4");
+  const int vec = dtype == NOVA_BF16 ? 8 : 4;
+  if (a.D % vec != 0 || a.D > 2048) return set_error(NOVA_ERR_SHAPE, "row_norm: D=%d unsupported (need D %% %d == 0, D <= 2048)", a.D, vec);
+  if (a.mod && (a.mod_ld % vec || (a.scale_off >= 0 && (a.scale_off % vec || a.shift_off % vec || a.shift_off < 0)) ||
+                (a.gate_off >= 0 && a.gate_off % vec)))
+    return set_error(NOVA_ERR_SHAPE, "row_norm: modulation offsets must be multiples of %d", vec);
   if ((a.gamma == nullptr) != (a.beta == nullptr)) return set_error(NOVA_ERR_ARG, "row_norm: gamma/beta must come together");
-  dim3 grid((unsigned)((a.rows + 3) / 4)), block(256);
+  dim3 grid((unsigned)((a.rows + 3) / 4));
   // algorithmic bytes: read in (+res, +mod terms) and write out once
   const double esz = dtype == NOVA_BF16 ? 2.0 : 4.0;
   const int nmod = a.mod ? ((a.scale_off >= 0 ? 2 : 0) + (a.gate_off >= 0 ? 1 : 0)) : 0;
   ProfScope prof(PROF_ROWNORM, esz * a.rows * a.D * (2.0 + (a.res ? 1 : 0) + nmod), st);
-  if (dtype == NOVA_BF16) hipLaunchKernelGGL(row_norm_kernel<bf16_t>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(row_norm_kernel<float>, grid, block, 0, st, a);
+  const int chunks = (a.D / vec + 63) / 64;  // 16-byte chunks per lane
+  if (dtype == NOVA_BF16) {
+    if (chunks <= 2) launch_row_norm<bf16_t, 2>(a, grid, st);
+    else launch_row_norm<bf16_t, 4>(a, grid, st);
+  } else {
+    if (chunks <= 4) launch_row_norm<float, 4>(a, grid, st);
+    else launch_row_norm<float, 8>(a, grid, st);
+  }
   return check_launch("row_norm");
 }
 
