@@ -54,6 +54,10 @@ int nova_check_device(void);
 int nova_prof_enable(int on);
 int nova_prof_collect(double* ms, double* work, long long* launches, int slots);
 
+/* Test hook: 0 = automatic choice between the 128x128 and the 256x256 (large-M) GEMM structures,
+ * 128 / 256 = force one (both compute bit-identical results; tests/test_gpu_kernels.py compares them). */
+int nova_debug_force_gemm_tile(int tile);
+
 /* ---- projection GEMM -----------------------------------------------------------------------
  * out[M,N] = act(A[M,K] * W[N,K]^T + bias[N])        W in nn.Linear layout.
  * Replaces nn.Linear (+ nn.GELU() / nn.SiLU()) at vision_transformer.py:33-38 (MLP.fc1/fc2),

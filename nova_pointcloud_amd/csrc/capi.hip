@@ -85,6 +85,12 @@ int nova_check_device(void) {
   return 0;
 }
 
+int nova_debug_force_gemm_tile(int tile) {
+  NOVA_REQUIRE(tile == 0 || tile == 128 || tile == 256, NOVA_ERR_ARG, "force_gemm_tile: 0, 128 or 256");
+  gemm_force_tile(tile);
+  return 0;
+}
+
 int nova_prof_enable(int on) {
   g_prof_on = on != 0;
   return 0;

@@ -129,24 +129,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
     }
   }
 
-  // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4)
+  // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4).
+  // Loads are batched (all bias vectors once, the 4 RoPE vectors of a row together) so their latencies
+  // overlap instead of serialising behind per-fragment branches.
+  f4v bv[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
+  if (e.bias) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wn * 64 + nf * 16 + fg * 4);
+  }
+  const bool rot = EPI == EPI_ROPE && n0 < e.rope_cols;  // tile-uniform: rope_cols is a multiple of the tile width
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf) {
     const int m = m0 + wm * 64 + mf * 16 + fr;
     if (m >= M) continue;
-    const float* ropem = nullptr;
-    if (EPI == EPI_ROPE) {
+    f4v cs[4];
+    if (rot) {
       const int s = m / e.L, l = m - s * e.L;
-      ropem = e.rope + ((size_t)(s % e.rope_batch) * e.L + l) * e.hd;  // hd/2 pairs x (cos, sin)
+      const float* ropem = e.rope + ((size_t)(s % e.rope_batch) * e.L + l) * e.hd;  // hd/2 pairs x (cos, sin)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) cs[nf] = *reinterpret_cast<const f4v*>(ropem + (n0 + wn * 64 + nf * 16 + fg * 4) % e.hd);
     }
+    T* dst = C + (size_t)m * N + n0 + wn * 64 + fg * 4;
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
-      const int n = n0 + wn * 64 + nf * 16 + fg * 4;
-      f4v v = acc[nf][mf];
-      if (e.bias) {
-        const f4v b = *reinterpret_cast<const f4v*>(e.bias + n);
-        v += b;
-      }
+      f4v v = acc[nf][mf] + bv[nf];
       if (EPI == EPI_GELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
@@ -154,26 +162,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
       } else if (EPI == EPI_ROPE) {
-        if (n < e.rope_cols) {
-          const int dd = n % e.hd;  // multiple of 4: pairs (dd, dd+1), (dd+2, dd+3)
-          const f4v cs = *reinterpret_cast<const f4v*>(ropem + dd);  // cos0, sin0, cos1, sin1
+        if (rot) {  // pairs (n, n+1), (n+2, n+3); cs = cos0, sin0, cos1, sin1
           const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-          v[0] = cs[0] * x0 - cs[1] * x1;
-          v[1] = cs[1] * x0 + cs[0] * x1;
-          v[2] = cs[2] * x2 - cs[3] * x3;
-          v[3] = cs[3] * x2 + cs[2] * x3;
+          v[0] = cs[nf][0] * x0 - cs[nf][1] * x1;
+          v[1] = cs[nf][1] * x0 + cs[nf][0] * x1;
+          v[2] = cs[nf][2] * x2 - cs[nf][3] * x3;
+          v[3] = cs[nf][3] * x2 + cs[nf][2] * x3;
         }
       }
-      T* dst = C + (size_t)m * N + n;
       if constexpr (sizeof(T) == 2) {
         u2v o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        *reinterpret_cast<u2v*>(dst) = o;
+        *reinterpret_cast<u2v*>(dst + nf * 16) = o;
       } else {
-        *reinterpret_cast<f4v*>(dst) = v;
+        *reinterpret_cast<f4v*>(dst + nf * 16) = v;
       }
     }
   }
 }
+
+// gemm256.hip: 256x256 ping-pong kernel for large M
+int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
+                   const float* rope, int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st);
+
+static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
+void gemm_force_tile(int tile) { g_force_tile = tile; }
 
 template <typename T>
 static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi& e,
@@ -182,6 +194,11 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
   if (M <= 0) return 0;
   if (N % BN != 0 || K % kelems != 0 || K <= 0)
     return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
+  const bool can256 = N % 256 == 0;
+  if (g_force_tile == 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
+  if (can256 && (g_force_tile == 256 || (g_force_tile == 0 && M >= 4096)))
+    return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols,
+                          sizeof(T) == 2 ? NOVA_BF16 : NOVA_F32, st);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(ntm * ntn), block(256);
   ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);

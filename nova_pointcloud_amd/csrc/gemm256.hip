@@ -1,0 +1,258 @@
+// NOVA hot path: large-M projection GEMM, 256x256 tile, ping-pong schedule.
+//
+// Same contract and epilogues as gemm.hip (out[M,N] = epi(A[M,K] W[N,K]^T + bias)); used for the encoder
+// GEMMs where M = S*L is in the tens of thousands and N is a multiple of 256.
+//
+// Why a second structure: the 128x128 kernel spends most of a K-step waiting on "LDS-DMA landed -> barrier"
+// (its MFMA pipe is ~35 % busy). Here one 512-thread workgroup per CU owns a 256x256 tile; its 8 waves form
+// two groups (wr = 0/1, one wave of each group on every SIMD) that run ONE BARRIER APART: while a group issues
+// its 16 MFMAs of a phase, the other group issues its LDS fragment reads and the next LDS-DMA prefetch, then they
+// swap. LDS-DMA stays in flight across barriers under a counted s_waitcnt vmcnt (never 0 in the loop).
+//
+// Phase plan. A K-tile (64 bf16 / 32 f32 per row) is staged as 4 units of 128 rows x 128 B:
+//   A(mi): rows {wr*128 + mi*64 + [0,64)}  of the A tile, for both wr      (what phase 0 / 2 read)
+//   W(ni): rows {wc*64  + ni*32 + [0,32)}  of the W tile, for all four wc  (what phases 0,3 / 1 read)
+// A wave (wr, wc) owns out[wr*128 + 128][wc*64 + 64] = 8 x 4 MFMA 16x16 fragments. Per K-tile, 4 phases:
+//   p0: read A(0), W(0) -> quadrant (0,0)   p1: read W(1) -> (0,1)   p2: read A(1) -> (1,1)   p3: read W(0) -> (1,0)
+// 16 MFMAs each. Staging order is A0, W1, A1, W0 per tile (flat index q = 4*tile + unit); phase p of tile t
+// issues q = 4t + p + 6, i.e. always the unit whose LDS slot (2 K-tile buffers x 4 units = 128 KiB) had its
+// last read TWO phases earlier - the distance that is safe for groups running one barrier apart.
+// One wait per K-tile: s_waitcnt vmcnt(4) before the first barrier of phase 3 retires everything but the two
+// youngest units (= all of tile t+1); the first read of tile t+1 happens in the next phase, one barrier later.
+#include "common.h"
+#include "nova_internal.h"
+
+namespace nova {
+
+constexpr int P_UNIT = 128 * 128;   // bytes of one staged unit (128 rows x 128 B)
+constexpr int P_BUF = 4 * P_UNIT;   // A(0) A(1) W(0) W(1)
+constexpr int P_LDS = 2 * P_BUF;    // 128 KiB
+
+struct GemmEpi;  // same POD as gemm.hip (redeclared below to keep the translation units independent)
+struct GemmEpi256 {
+  const float* bias;
+  const float* rope;
+  int L, rope_batch, hd, rope_cols;
+};
+
+enum { E_NONE = 0, E_GELU = 1, E_SILU = 2, E_ROPE = 3 };
+
+template <typename T> struct PFrag;
+template <> struct PFrag<bf16_t> { bf8v v; };
+template <> struct PFrag<float> { f4v v; };
+
+__device__ __forceinline__ f4v pmma(const PFrag<bf16_t>& w, const PFrag<bf16_t>& a, f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f4v pmma(const PFrag<float>& w, const PFrag<float>& a, f4v c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[j], a.v[j], c, 0, 0, 0);
+  return c;
+}
+
+template <typename T>
+__device__ __forceinline__ PFrag<T> punit_frag(const char* unit, int row, int chunk) {
+  PFrag<T> f;
+  f.v = *reinterpret_cast<const decltype(f.v)*>(unit + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+  return f;
+}
+
+#define NOVA_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                         T* __restrict__ C, int M, int N, int K, int ntm, int ntn,
+                                                         GemmEpi256 e) {
+  __shared__ __attribute__((aligned(16))) char smem[P_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  const int nwg = ntm * ntn;
+  const int t = xcd_remap(blockIdx.x, nwg);
+  constexpr int GM = 8;
+  const int per_group = GM * ntn;
+  const int group = t / per_group, first_m = group * GM;
+  const int gsz = min(ntm - first_m, GM);
+  const int tm = first_m + (t % per_group) % gsz;
+  const int tn = (t % per_group) / gsz;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  // ---- per-lane source pointers of the two LDS-DMA pieces this wave moves for each of the 4 units
+  // unit order u: 0 = A(0), 1 = W(1), 2 = A(1), 3 = W(0)   (the staging order)
+  const int cp = lane & 7;
+  const size_t rowbytes = (size_t)K * sizeof(T);
+  const char* src[4][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wid * 2 + i) * 8 + (lane >> 3);          // row inside the unit, 0..127
+    const int c = (cp ^ ((r >> 1) & 7)) << 4;               // source chunk (swizzle on the source side)
+    const int a_lo = (r >> 6) * 128 + (r & 63);             // + mi*64
+    const int w_lo = (r >> 5) * 64 + (r & 31);              // + ni*32
+    src[0][i] = reinterpret_cast<const char*>(A) + (size_t)min(m0 + a_lo, M - 1) * rowbytes + c;
+    src[2][i] = reinterpret_cast<const char*>(A) + (size_t)min(m0 + a_lo + 64, M - 1) * rowbytes + c;
+    src[3][i] = reinterpret_cast<const char*>(W) + (size_t)(n0 + w_lo) * rowbytes + c;
+    src[1][i] = reinterpret_cast<const char*>(W) + (size_t)(n0 + w_lo + 32) * rowbytes + c;
+  }
+  const int nkt = K / (128 / (int)sizeof(T));
+  // LDS offset of unit u inside a buffer: A(0) A(1) W(0) W(1)
+  auto unit_off = [](int u) { return (u == 0 ? 0 : u == 2 ? 1 : u == 3 ? 2 : 3) * P_UNIT; };
+  auto stage = [&](int u, int kt) {  // all 8 waves: 2 LDS-DMA instructions each (wave-uniform condition)
+    if (kt < nkt) {
+      char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048;
+      __builtin_amdgcn_global_load_lds(src[u][0] + (size_t)kt * 128, NOVA_LDS_PTR(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(src[u][1] + (size_t)kt * 128, NOVA_LDS_PTR(dst + 1024), 16, 0, 0);
+    }
+  };
+
+  f4v acc[4][8];  // [nf][mf]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- prologue: q = 0..5 = tile 0 (A0 W1 A1 W0) + tile 1 (A0 W1); wait for tile 0
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  stage(0, 1); stage(1, 1);
+  if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NOVA_BARRIER();
+  if (wr == 1) NOVA_BARRIER();  // group 1 runs one barrier behind group 0 from here on
+
+  PFrag<T> af[4][2], wf[2][2];
+  auto read_a = [&](const char* buf, int mi) {
+    const char* u = buf + mi * P_UNIT;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) af[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
+  };
+  auto read_w = [&](const char* buf, int ni) {
+    const char* u = buf + (2 + ni) * P_UNIT;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) wf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
+  };
+  auto mma_quadrant = [&](int mi, int ni) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], acc[ni * 2 + nf][mi * 4 + mf]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const char* buf = smem + (kt & 1) * P_BUF;
+    // phase 0: quadrant (0,0); stage q = 4kt+6 = (kt+1, A1)
+    read_a(buf, 0);
+    read_w(buf, 0);
+    stage(2, kt + 1);
+    NOVA_BARRIER();
+    mma_quadrant(0, 0);
+    NOVA_BARRIER();
+    // phase 1: quadrant (0,1); stage (kt+1, W0)
+    read_w(buf, 1);
+    stage(3, kt + 1);
+    NOVA_BARRIER();
+    mma_quadrant(0, 1);
+    NOVA_BARRIER();
+    // phase 2: quadrant (1,1); stage (kt+2, A0)
+    read_a(buf, 1);
+    stage(0, kt + 2);
+    NOVA_BARRIER();
+    mma_quadrant(1, 1);
+    NOVA_BARRIER();
+    // phase 3: quadrant (1,0); stage (kt+2, W1); retire all of tile kt+1 before the first barrier
+    read_w(buf, 0);
+    stage(1, kt + 2);
+    if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NOVA_BARRIER();
+    mma_quadrant(1, 0);
+    NOVA_BARRIER();
+  }
+  if (wr == 0) NOVA_BARRIER();  // re-align the groups
+
+  // ---- epilogue (same lane-local form as gemm.hip): lane holds out[m][n..n+3]
+  f4v bv[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
+  if (e.bias) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
+  }
+  const bool rot = EPI == E_ROPE && n0 < e.rope_cols;
+#pragma unroll
+  for (int mf = 0; mf < 8; ++mf) {
+    const int m = m0 + wr * 128 + mf * 16 + fr;
+    if (m >= M) continue;
+    f4v cs[4];
+    if (rot) {
+      const int s = m / e.L, l = m - s * e.L;
+      const float* ropem = e.rope + ((size_t)(s % e.rope_batch) * e.L + l) * e.hd;
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) cs[nf] = *reinterpret_cast<const f4v*>(ropem + (n0 + wc * 64 + nf * 16 + fg * 4) % e.hd);
+    }
+    T* dst = C + (size_t)m * N + n0 + wc * 64 + fg * 4;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      f4v v = acc[nf][mf] + bv[nf];
+      if (EPI == E_GELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
+      } else if (EPI == E_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
+      } else if (EPI == E_ROPE) {
+        if (rot) {
+          const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+          v[0] = cs[nf][0] * x0 - cs[nf][1] * x1;
+          v[1] = cs[nf][1] * x0 + cs[nf][0] * x1;
+          v[2] = cs[nf][2] * x2 - cs[nf][3] * x3;
+          v[3] = cs[nf][3] * x2 + cs[nf][2] * x3;
+        }
+      }
+      if constexpr (sizeof(T) == 2) {
+        u2v o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *reinterpret_cast<u2v*>(dst + nf * 16) = o;
+      } else {
+        *reinterpret_cast<f4v*>(dst + nf * 16) = v;
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch256(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
+                     hipStream_t st) {
+  const int ntm = (M + 255) / 256, ntn = N / 256;
+  dim3 grid(ntm * ntn), block(512);
+  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  const T* a = static_cast<const T*>(A);
+  const T* w = static_cast<const T*>(W);
+  T* c = static_cast<T*>(C);
+  switch (epi) {
+    case E_NONE: hipLaunchKernelGGL((gemm256_kernel<T, E_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_GELU: hipLaunchKernelGGL((gemm256_kernel<T, E_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_SILU: hipLaunchKernelGGL((gemm256_kernel<T, E_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_ROPE: hipLaunchKernelGGL((gemm256_kernel<T, E_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    default: return set_error(NOVA_ERR_ARG, "gemm256: unknown epilogue %d", epi);
+  }
+  return check_launch("gemm256");
+}
+
+// Entry used by gemm.hip's dispatcher. Preconditions (checked by the caller): N % 256 == 0,
+// K % (128 / sizeof(T)) == 0, K > 0, M > 0.
+int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
+                   const float* rope, int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st) {
+  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols};
+  return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st) : launch256<float>(A, W, C, M, N, K, epi, e, st);
+}
+
+}  // namespace nova

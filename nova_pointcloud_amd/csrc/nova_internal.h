@@ -26,6 +26,8 @@ int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, in
 int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L,
                   int D, int heads, int rope_batch, int dtype, hipStream_t st);
 
+void gemm_force_tile(int tile);
+
 // ---- attn.hip
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
              long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st);

@@ -68,6 +68,7 @@ SIGNATURES = {
                              ctypes.POINTER(c_float)] + [c_int] * 6 + [c_void_p] * 6 + [c_int, c_void_p],
 }
 SIGNATURES["nova_prof_enable"] = [c_int]
+SIGNATURES["nova_debug_force_gemm_tile"] = [c_int]
 SIGNATURES["nova_prof_collect"] = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_longlong), c_int]
 PROF_SLOTS = ["gemm_bias", "gemm_bias_gelu", "gemm_bias_silu", "qkv_gemm_rope", "attention", "row_norm"]
