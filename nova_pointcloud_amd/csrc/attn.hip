@@ -29,7 +29,7 @@ constexpr int A_KV = 64;             // keys per tile
 constexpr int A_ROWB = 128;          // bytes per K/V row (64 x bf16)
 constexpr int A_TILE = A_KV * A_ROWB;  // 8 KiB
 
-__global__ __launch_bounds__(256) void attn_bf16_hd64(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                       const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int Lq,
                                                       int Lk, long q_rs, long kv_rs, long o_rs, float c) {
   __shared__ __attribute__((aligned(16))) char smem[4 * A_TILE];  // [buf][K|V]
@@ -86,16 +86,15 @@ __global__ __launch_bounds__(256) void attn_bf16_hd64(const bf16_t* __restrict__
 
     // ---- S^T[key][q] for the two 32-key blocks
     f16v st[2];
+    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) st[kb][i] = 0.f;
       const int row = kb * 32 + r;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int phys = (2 * ks + hh) ^ ((row >> 1) & 7);
         const bf8v kf = *reinterpret_cast<const bf8v*>(tk + row * A_ROWB + phys * 16);
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[kb], 0, 0, 0);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : st[kb], 0, 0, 0);
       }
     }
     if (kt == nkt - 1 && (Lk & (A_KV - 1)) != 0) {  // ragged last tile: keys >= Lk contribute nothing
@@ -132,13 +131,18 @@ __global__ __launch_bounds__(256) void attn_bf16_hd64(const bf16_t* __restrict__
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
+      for (int s2 = 0; s2 < 2; ++s2) {
+        u4v packed;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float p = __builtin_amdgcn_exp2f(st[kb][8 * s2 + j] * c - mc);
-          psum += p;
-          pb[kb][s2][j] = (__bf16)p;
+        for (int j = 0; j < 4; ++j) {  // two probabilities -> one v_cvt_pk_bf16_f32
+          const float p0 = __builtin_amdgcn_exp2f(st[kb][8 * s2 + 2 * j] * c - mc);
+          const float p1 = __builtin_amdgcn_exp2f(st[kb][8 * s2 + 2 * j + 1] * c - mc);
+          psum += p0 + p1;
+          const bf2v h = __builtin_convertvector(f2v{p0, p1}, bf2v);
+          packed[j] = __builtin_bit_cast(uint32_t, h);
         }
+        pb[kb][s2] = __builtin_bit_cast(bf8v, packed);
+      }
     l_run += psum;
 
     // ---- O^T[dv][q] += V^T[dv][key] P^T[key][q]

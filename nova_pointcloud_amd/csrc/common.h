@@ -8,6 +8,8 @@ namespace nova {
 typedef __attribute__((ext_vector_type(8))) short s8v;   // 8 x bf16 bit patterns (one MFMA A/B fragment)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8v;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf4v;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2v;
+typedef __attribute__((ext_vector_type(2))) float f2v;
 typedef __attribute__((ext_vector_type(4))) short s4v;
 typedef __attribute__((ext_vector_type(4))) float f4v;
 typedef __attribute__((ext_vector_type(16))) float f16v;
