@@ -31,12 +31,17 @@ constexpr int A_TILE = A_KV * A_ROWB;  // 8 KiB
 
 __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                       const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int Lq,
-                                                      int Lk, long q_rs, long kv_rs, long o_rs, float c) {
+                                                      int Lk, long q_rs, long kv_rs, long o_rs, float c, int heads,
+                                                      int nq) {
   __shared__ __attribute__((aligned(16))) char smem[4 * A_TILE];  // [buf][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.y, s = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wid * 32;
+  // XCD-aware order: all query tiles of one (sequence, head) are consecutive in the remapped list, so they
+  // run on one XCD and its K/V (2 * Lk * 128 B) is served from that XCD's L2 after the first tile.
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int sh = t / nq, qt = t - sh * nq;
+  const int head = sh % heads, s = sh / heads;
+  const int q0 = qt * 128 + wid * 32;
 
   const bf16_t* qb = q + (size_t)s * Lq * q_rs + head * 64;
   const bf16_t* kb_ = k + (size_t)s * Lk * kv_rs + head * 64;
@@ -310,13 +315,15 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
   const int align = dtype == NOVA_BF16 ? 8 : 4;  // 16-byte row alignment for the vector loads
   if (q_rs % align || kv_rs % align || o_rs % align) return set_error(NOVA_ERR_SHAPE, "attn_fwd: row strides must be 16-byte multiples");
-  if (S > 65535 || heads > 65535) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
+  if (S > 65535 || heads > 65535 || (long)((Lq + 127) / 128) * heads * S > 0x7fffffffL)
+    return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
   const float c = scale * 1.4426950408889634f;
   dim3 grid((Lq + 127) / 128, heads, S), block(256);
   ProfScope prof(PROF_ATTN, 4.0 * S * heads * (double)Lq * Lk * hd, st);
   if (dtype == NOVA_BF16) {
-    hipLaunchKernelGGL(attn_bf16_hd64, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                       (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);
+    const int nq = (Lq + 127) / 128;
+    hipLaunchKernelGGL(attn_bf16_hd64, dim3((unsigned)((long)nq * heads * S)), block, 0, st, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, c, heads, nq);
   } else {
     hipLaunchKernelGGL(attn_f32_hd64, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v,
                        (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);

@@ -184,8 +184,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st);
 
+void gemm256_set_variant(int v);
 static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
-void gemm_force_tile(int tile) { g_force_tile = tile; }
+void gemm_force_tile(int tile) {
+  if (tile >= 2560) {  // 2560 + v: force the 256 tile with schedule variant v (A/B experiments)
+    gemm256_set_variant(tile - 2560);
+    tile = 256;
+  }
+  g_force_tile = tile;
+}
 
 template <typename T>
 static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi& e,

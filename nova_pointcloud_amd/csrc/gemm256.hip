@@ -10,15 +10,20 @@
 // swap. LDS-DMA stays in flight across barriers under a counted s_waitcnt vmcnt (never 0 in the loop).
 //
 // Phase plan. A K-tile (64 bf16 / 32 f32 per row) is staged as 4 units of 128 rows x 128 B:
-//   A(mi): rows {wr*128 + mi*64 + [0,64)}  of the A tile, for both wr      (what phase 0 / 2 read)
-//   W(ni): rows {wc*64  + ni*32 + [0,32)}  of the W tile, for all four wc  (what phases 0,3 / 1 read)
+//   A(mi): rows {wr*128 + mi*64 + [0,64)}  of the A tile, for both wr      (read in phase 0 / 2)
+//   W(ni): rows {wc*64  + ni*32 + [0,32)}  of the W tile, for all four wc  (read in phase 0 / 1)
 // A wave (wr, wc) owns out[wr*128 + 128][wc*64 + 64] = 8 x 4 MFMA 16x16 fragments. Per K-tile, 4 phases:
-//   p0: read A(0), W(0) -> quadrant (0,0)   p1: read W(1) -> (0,1)   p2: read A(1) -> (1,1)   p3: read W(0) -> (1,0)
-// 16 MFMAs each. Staging order is A0, W1, A1, W0 per tile (flat index q = 4*tile + unit); phase p of tile t
-// issues q = 4t + p + 6, i.e. always the unit whose LDS slot (2 K-tile buffers x 4 units = 128 KiB) had its
-// last read TWO phases earlier - the distance that is safe for groups running one barrier apart.
-// One wait per K-tile: s_waitcnt vmcnt(4) before the first barrier of phase 3 retires everything but the two
-// youngest units (= all of tile t+1); the first read of tile t+1 happens in the next phase, one barrier later.
+//   p0: read A(0), W(0) -> quadrant (0,0)   p1: read W(1) -> (0,1)   p2: read A(1) -> (1,1)
+//   p3: no LDS reads, quadrant (1,0) on the W(0) fragments kept in registers since p0
+// 16 MFMAs each (8 independent accumulators per k-half). Staging order is A0, W1, A1, W0 per tile (flat index
+// q = 4*tile + unit); phase p of tile t issues q = 4t + p + 6, i.e. always the unit whose LDS slot (2 K-tile
+// buffers x 4 units = 128 KiB) had its last read at least TWO phases earlier - the distance that is safe for
+// groups running one barrier apart with the fragment-read wait placed after the phase's first barrier.
+// One wait per K-tile: a counted s_waitcnt vmcnt before the first barrier of phase 3 retires everything but the
+// youngest unit(s) (= all of tile t+1); the first read of tile t+1 happens in the next phase, one barrier later.
+// Epilogue: bias/GELU/SiLU/RoPE lane-local as in gemm.hip; bf16 results of two fragments are exchanged with
+// v_permlane16_swap so every lane stores 16 contiguous bytes (half the store instructions of the 8-byte form).
+// Results are bit-identical to gemm.hip (same MFMA, same k order): tests/test_gpu_kernels.py compares them.
 #include "common.h"
 #include "nova_internal.h"
 
@@ -59,7 +64,10 @@ __device__ __forceinline__ PFrag<T> punit_frag(const char* unit, int row, int ch
 
 #define NOVA_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <typename T, int EPI>
+// VAR selects where the two LDS-DMA instructions of a phase are issued (A/B-tested on the GPU, tools/microbench.py):
+//   0: both between the two k-halves of the MFMA segment   1: one in the load segment, one in the MFMA segment
+//   2: both in the load segment after the fragment reads   3: both in the load segment before the fragment reads
+template <typename T, int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                          T* __restrict__ C, int M, int N, int K, int ntm, int ntn,
                                                          GemmEpi256 e) {
@@ -97,12 +105,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   const int nkt = K / (128 / (int)sizeof(T));
   // LDS offset of unit u inside a buffer: A(0) A(1) W(0) W(1)
   auto unit_off = [](int u) { return (u == 0 ? 0 : u == 2 ? 1 : u == 3 ? 2 : 3) * P_UNIT; };
-  auto stage = [&](int u, int kt) {  // all 8 waves: 2 LDS-DMA instructions each (wave-uniform condition)
+  auto stage_piece = [&](int u, int kt, int i) {
     if (kt < nkt) {
-      char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048;
-      __builtin_amdgcn_global_load_lds(src[u][0] + (size_t)kt * 128, NOVA_LDS_PTR(dst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(src[u][1] + (size_t)kt * 128, NOVA_LDS_PTR(dst + 1024), 16, 0, 0);
+      char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048 + i * 1024;
+      __builtin_amdgcn_global_load_lds(src[u][i] + (size_t)kt * 128, NOVA_LDS_PTR(dst), 16, 0, 0);
     }
+  };
+  auto stage = [&](int u, int kt) {  // all 8 waves: 2 LDS-DMA instructions each (wave-uniform condition)
+    stage_piece(u, kt, 0);
+    stage_piece(u, kt, 1);
   };
 
   f4v acc[4][8];  // [nf][mf]
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   NOVA_BARRIER();
   if (wr == 1) NOVA_BARRIER();  // group 1 runs one barrier behind group 0 from here on
 
-  PFrag<T> af[4][2], wf[2][2];
+  PFrag<T> af[4][2], wf0[2][2], wf1[2][2];
   auto read_a = [&](const char* buf, int mi) {
     const char* u = buf + mi * P_UNIT;
 #pragma unroll
@@ -129,52 +140,75 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) af[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
   };
-  auto read_w = [&](const char* buf, int ni) {
+  auto read_w = [&](const char* buf, int ni, PFrag<T> (&wf)[2][2]) {
     const char* u = buf + (2 + ni) * P_UNIT;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) wf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
   };
-  auto mma_quadrant = [&](int mi, int ni) {
+  // 16 MFMAs of one quadrant; the LDS-DMA prefetch of this phase is issued between the two k halves, where
+  // its issue cost hides under the matrix pipe instead of lengthening the other group's critical load segment.
+  auto mma_quadrant = [&](int mi, int ni, PFrag<T> (&wf)[2][2], int su, int skt) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
         for (int mf = 0; mf < 4; ++mf) acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], acc[ni * 2 + nf][mi * 4 + mf]);
+      if (kk == 0) {
+        if (VAR == 0) stage(su, skt);
+        if (VAR == 1) stage_piece(su, skt, 1);
+      }
+    }
     __builtin_amdgcn_s_setprio(0);
   };
 
+  auto lstage_pre = [&](int u, int kt) { if (VAR == 3) stage(u, kt); };
+  auto lstage_post = [&](int u, int kt) {
+    if (VAR == 2) stage(u, kt);
+    if (VAR == 1) stage_piece(u, kt, 0);
+  };
   for (int kt = 0; kt < nkt; ++kt) {
     const char* buf = smem + (kt & 1) * P_BUF;
-    // phase 0: quadrant (0,0); stage q = 4kt+6 = (kt+1, A1)
+    // phase 0: quadrant (0,0); stages q = 4kt+6 = (kt+1, A1)
+    lstage_pre(2, kt + 1);
     read_a(buf, 0);
-    read_w(buf, 0);
-    stage(2, kt + 1);
+    read_w(buf, 0, wf0);
+    lstage_post(2, kt + 1);
     NOVA_BARRIER();
-    mma_quadrant(0, 0);
+    mma_quadrant(0, 0, wf0, 2, kt + 1);
     NOVA_BARRIER();
-    // phase 1: quadrant (0,1); stage (kt+1, W0)
-    read_w(buf, 1);
-    stage(3, kt + 1);
+    // phase 1: quadrant (0,1); stages (kt+1, W0)
+    lstage_pre(3, kt + 1);
+    read_w(buf, 1, wf1);
+    lstage_post(3, kt + 1);
     NOVA_BARRIER();
-    mma_quadrant(0, 1);
+    mma_quadrant(0, 1, wf1, 3, kt + 1);
     NOVA_BARRIER();
-    // phase 2: quadrant (1,1); stage (kt+2, A0)
+    // phase 2: quadrant (1,1); stages (kt+2, A0)
+    lstage_pre(0, kt + 2);
     read_a(buf, 1);
-    stage(0, kt + 2);
+    lstage_post(0, kt + 2);
     NOVA_BARRIER();
-    mma_quadrant(1, 1);
+    mma_quadrant(1, 1, wf1, 0, kt + 2);
     NOVA_BARRIER();
-    // phase 3: quadrant (1,0); stage (kt+2, W1); retire all of tile kt+1 before the first barrier
-    read_w(buf, 0);
-    stage(1, kt + 2);
-    if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // phase 3: quadrant (1,0) on the W(0) fragments still held from phase 0 (no LDS reads); stages (kt+2, W1).
+    // Before the first barrier: retire all of tile kt+1 = everything but the youngest unit issued so far
+    // ((kt+2, A0) of phase 2; this phase's unit is issued after the barrier).
+    // (VAR 1: one more piece of this phase's unit is already issued -> 3; VAR 2/3: the whole unit -> 4)
+    lstage_pre(1, kt + 2);
+    lstage_post(1, kt + 2);
+    if (kt + 2 < nkt) {
+      if (VAR == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if (VAR == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if (VAR >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     NOVA_BARRIER();
-    mma_quadrant(1, 0);
+    mma_quadrant(1, 0, wf0, 1, kt + 2);
     NOVA_BARRIER();
   }
   if (wr == 0) NOVA_BARRIER();  // re-align the groups
@@ -190,8 +224,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   const bool rot = EPI == E_ROPE && n0 < e.rope_cols;
 #pragma unroll
   for (int mf = 0; mf < 8; ++mf) {
-    const int m = m0 + wr * 128 + mf * 16 + fr;
-    if (m >= M) continue;
+    const int m_raw = m0 + wr * 128 + mf * 16 + fr;
+    if (__builtin_amdgcn_readfirstlane(m0 + wr * 128 + mf * 16) >= M) continue;  // whole fragment row block past M (wave-uniform)
+    const int m = min(m_raw, M - 1);  // lanes past M recompute row M-1 and store the identical bytes (benign)
     f4v cs[4];
     if (rot) {
       const int s = m / e.L, l = m - s * e.L;
@@ -200,6 +235,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
       for (int nf = 0; nf < 4; ++nf) cs[nf] = *reinterpret_cast<const f4v*>(ropem + (n0 + wc * 64 + nf * 16 + fg * 4) % e.hd);
     }
     T* dst = C + (size_t)m * N + n0 + wc * 64 + fg * 4;
+    u2v pk[4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
       f4v v = acc[nf][mf] + bv[nf];
@@ -219,17 +255,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
         }
       }
       if constexpr (sizeof(T) == 2) {
-        u2v o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-        *reinterpret_cast<u2v*>(dst + nf * 16) = o;
+        pk[nf] = u2v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
       } else {
         *reinterpret_cast<f4v*>(dst + nf * 16) = v;
+      }
+    }
+    if constexpr (sizeof(T) == 2) {
+      // widen the store: v_permlane16_swap exchanges the odd 16-lane rows of fragment a with the even rows of
+      // fragment b, after which a lane holds 8 consecutive bf16 columns -> one 16-byte store per fragment pair
+      // (lanes with fg even: fragment a, fg odd: fragment b; columns 8*(fg>>1) .. +7 of that fragment).
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+        u4v o = {lo[0], hi[0], lo[1], hi[1]};
+        *reinterpret_cast<u4v*>(C + (size_t)m * N + n0 + wc * 64 + (2 * pr + (fg & 1)) * 16 + (fg >> 1) * 8) = o;
       }
     }
   }
 }
 
-template <typename T>
-static int launch256(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
+static int g_var256 = 2;  // measured best (tools/gemm_variants.py): LDS-DMA issued in the load segment, after the reads
+void gemm256_set_variant(int v) { g_var256 = v; }
+
+template <typename T, int VAR>
+static int launch256v(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
                      hipStream_t st) {
   const int ntm = (M + 255) / 256, ntn = N / 256;
   dim3 grid(ntm * ntn), block(512);
@@ -238,13 +288,24 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
   const T* w = static_cast<const T*>(W);
   T* c = static_cast<T*>(C);
   switch (epi) {
-    case E_NONE: hipLaunchKernelGGL((gemm256_kernel<T, E_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
-    case E_GELU: hipLaunchKernelGGL((gemm256_kernel<T, E_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
-    case E_SILU: hipLaunchKernelGGL((gemm256_kernel<T, E_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
-    case E_ROPE: hipLaunchKernelGGL((gemm256_kernel<T, E_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_NONE: hipLaunchKernelGGL((gemm256_kernel<T, E_NONE, VAR>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_GELU: hipLaunchKernelGGL((gemm256_kernel<T, E_GELU, VAR>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_SILU: hipLaunchKernelGGL((gemm256_kernel<T, E_SILU, VAR>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_ROPE: hipLaunchKernelGGL((gemm256_kernel<T, E_ROPE, VAR>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     default: return set_error(NOVA_ERR_ARG, "gemm256: unknown epilogue %d", epi);
   }
   return check_launch("gemm256");
+}
+
+template <typename T>
+static int launch256(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
+                     hipStream_t st) {
+  switch (g_var256) {
+    case 1: return launch256v<T, 1>(A, W, C, M, N, K, epi, e, st);
+    case 3: return launch256v<T, 3>(A, W, C, M, N, K, epi, e, st);
+    case 0: return launch256v<T, 0>(A, W, C, M, N, K, epi, e, st);
+    default: return launch256v<T, 2>(A, W, C, M, N, K, epi, e, st);
+  }
 }
 
 // Entry used by gemm.hip's dispatcher. Preconditions (checked by the caller): N % 256 == 0,
