@@ -76,6 +76,13 @@ int nova_gemm_bias_act(const void* A, const void* W, const float* bias, void* ou
 int nova_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L, int D,
                   int heads, int rope_batch, int dtype, void* stream);
 
+/* Generalisation used for the last encoder block, whose output is only consumed at the rows predicted in the
+ * current AR step (transformer_3d.py:129-132 -> diffusion_mlp.py:93): out[M,N] = x[M,K] W[N,K]^T + bias with columns
+ * [0, rope_cols) rotated by rope[(m / L) % rope_batch, m % L] (heads of width head_dim). The engine calls it once with
+ * the K|V rows of attn.qkv.weight over all tokens (rope_cols = D) and once with the Q rows over the n gathered rows. */
+int nova_qkv_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
+                       int L, int rope_batch, int head_dim, int rope_cols, int dtype, void* stream);
+
 /* rope[nb, pad + n_tok, hd/2, 2] from integer grid positions (embeddings.py:59-67 get_func):
  * pos [n_pos,3] (t,h,w); ids [nb,n_tok] int64 gathers token -> position (NULL: identity);
  * the first `pad` rows (condition prefix) sit at position 0; inv_freq [hd/2] = 1 / theta^scale

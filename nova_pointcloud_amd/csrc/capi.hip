@@ -126,6 +126,15 @@ int nova_qkv_rope(const void* x, const void* Wqkv, const float* bias, const floa
   return gemm_qkv_rope(x, Wqkv, bias, rope, qkv, S, L, D, heads, rope_batch, dtype, (hipStream_t)stream);
 }
 
+int nova_qkv_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
+                       int L, int rope_batch, int head_dim, int rope_cols, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "qkv_rope_cols: bad dtype %d", dtype);
+  NOVA_REQUIRE(M == 0 || (x && W && out), NOVA_ERR_ARG, "qkv_rope_cols: null pointer");
+  NOVA_REQUIRE(L > 0 && head_dim > 0 && head_dim % 4 == 0 && rope_cols % 128 == 0 && rope_cols <= N, NOVA_ERR_SHAPE,
+               "qkv_rope_cols: bad L/head_dim/rope_cols");
+  return gemm_rope_cols(x, W, bias, rope, out, M, N, K, L, rope_batch, head_dim, rope_cols, dtype, (hipStream_t)stream);
+}
+
 int nova_rope_table(const float* pos, const long long* ids, float* rope, int nb, int pad, int n_tok, int n_pos, int hd,
                     const float* inv_freq, void* stream) {
   NOVA_REQUIRE(pos && rope && inv_freq, NOVA_ERR_ARG, "rope_table: null pointer");

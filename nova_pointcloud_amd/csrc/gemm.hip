@@ -201,7 +201,7 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
   if (M <= 0) return 0;
   if (N % BN != 0 || K % kelems != 0 || K <= 0)
     return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
-  const bool can256 = N % 256 == 0;
+  const bool can256 = N % 256 == 0 && (epi != EPI_ROPE || e.rope_cols % 256 == 0);  // rotation is decided per tile
   if (g_force_tile == 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
   if (can256 && (g_force_tile == 256 || (g_force_tile == 0 && M >= 4096)))
     return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols,
@@ -239,6 +239,14 @@ int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const floa
   GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, 2 * D};
   return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st)
                             : launch_gemm<float>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st);
+}
+
+int gemm_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
+                   int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st) {
+  if (rope && rope_batch <= 0) return set_error(NOVA_ERR_ARG, "rope_cols: rope_batch must be > 0");
+  GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, rope_cols};
+  const int epi = rope ? EPI_ROPE : EPI_NONE;
+  return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(x, W, out, M, N, K, epi, e, st) : launch_gemm<float>(x, W, out, M, N, K, epi, e, st);
 }
 
 }  // namespace nova

@@ -26,6 +26,8 @@ int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, in
 int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L,
                   int D, int heads, int rope_batch, int dtype, hipStream_t st);
 
+int gemm_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
+                   int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st);
 void gemm_force_tile(int tile);
 
 // ---- attn.hip

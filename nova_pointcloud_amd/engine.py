@@ -144,6 +144,20 @@ class NovaEngine(object):
         half = ie.encoder_depth
         self.enc1 = pack_vit_blocks(list(ie.blocks[:half]), dtype)
         self.enc2 = pack_vit_blocks(list(ie.blocks[half:]), dtype)
+        # The LAST encoder block is only consumed at the rows predicted in this AR step (final LN + decoder read
+        # nothing else), so everything but its K/V projection runs on those n rows only (same math per row).
+        self.enc2_head = pack_vit_blocks(list(ie.blocks[half:-1]), dtype) if len(ie.blocks) - half > 1 else None
+        lb = ie.blocks[-1]
+        lpk = self.last = _Pack()
+        W, Bq = lb.attn.qkv.weight.detach(), lb.attn.qkv.bias.detach()
+        Dm = W.shape[1]
+        lpk.q = (lpk.w(W[:Dm], dtype), lpk.f(Bq[:Dm]))
+        lpk.kv = (lpk.w(W[Dm:], dtype), lpk.f(Bq[Dm:]))
+        lpk.proj = (lpk.w(lb.attn.proj.weight, dtype), lpk.f(lb.attn.proj.bias))
+        lpk.fc1 = (lpk.w(lb.mlp.fc1.weight, dtype), lpk.f(lb.mlp.fc1.bias))
+        lpk.fc2 = (lpk.w(lb.mlp.fc2.weight, dtype), lpk.f(lb.mlp.fc2.bias))
+        lpk.n1 = (lpk.f(lb.norm1.weight), lpk.f(lb.norm1.bias))
+        lpk.n2 = (lpk.f(lb.norm2.weight), lpk.f(lb.norm2.bias))
         self.dec = pack_decoder(de, dtype)
         pk = self.misc = _Pack()
         te = m.text_embed
@@ -194,6 +208,35 @@ class NovaEngine(object):
     def _sequence(self, out, prefix, prefix_rows, tokens, tok_rows, ids, S, B, Lp, n_sel):
         hip.call("nova_build_sequence", hip.ptr(prefix) if Lp else None, prefix_rows, hip.ptr(tokens) if n_sel else None,
                  tok_rows, hip.ptr(ids), out.data_ptr(), S, B, Lp, n_sel, self.D, self.code, hip.stream_ptr())
+
+    def _last_block_rows(self, x2, S, B, L, Nv, n, pred_ids, pos_img, inv_freq, rope_full, hd, ws):
+        """Block.forward (vision_transformer.py:89-92) of the last encoder block for the n predicted rows only:
+        K/V projected for all L rows, Q / attention / proj / LN / MLP for [S*n] gathered rows. Returns y [S*n, D]."""
+        D, code, st, lp = self.D, self.code, hip.stream_ptr, self.last
+        es = x2.element_size()
+        # K,V for every token: x2 [S*L, D] x Wkv^T -> kv [S*L, 2D], RoPE on the K half
+        kv = ws["qkv"].view(-1)[: S * L * 2 * D].view(S * L, 2 * D)
+        hip.call("nova_qkv_rope_cols", x2.data_ptr(), lp.kv[0], lp.kv[1], hip.ptr(rope_full), kv.data_ptr(), S * L, 2 * D, D,
+                 L, 1, hd, D, code, st())
+        # the predicted rows of every sequence (cond and uncond share pred_ids)
+        ids = torch.cat([pred_ids] * (S // B)).contiguous()  # [S, n]
+        xq = torch.empty(S * n, D, dtype=x2.dtype, device=x2.device)
+        hip.call("nova_build_sequence", None, 0, x2.data_ptr() + Nv * D * es, L, ids.data_ptr(), xq.data_ptr(), S, S, 0, n, D,
+                 code, st())
+        rope_q = hip.rope_table(pos_img, pred_ids, 0, inv_freq, B, hd) if pos_img is not None else None
+        q = torch.empty(S * n, D, dtype=x2.dtype, device=x2.device)
+        hip.call("nova_qkv_rope_cols", xq.data_ptr(), lp.q[0], lp.q[1], hip.ptr(rope_q), q.data_ptr(), S * n, D, D, n,
+                 B if rope_q is not None else 1, hd, D, code, st())
+        o = torch.empty_like(q)
+        hip.call("nova_attn_fwd", q.data_ptr(), kv.data_ptr(), kv.data_ptr() + D * es, o.data_ptr(), S, self.heads, n, L, hd,
+                 D, 2 * D, D, float(hd) ** -0.5, code, st())
+        a = self._gemm(o, lp.proj[0], lp.proj[1], D)
+        hip.call("nova_row_norm", a.data_ptr(), xq.data_ptr(), lp.n1[0], lp.n1[1], None, 0, -1, -1, -1, xq.data_ptr(), None, S * n,
+                 D, 1e-5, code, st())
+        h = self._gemm(self._gemm(xq, lp.fc1[0], lp.fc1[1], self.hidden, hip.ACT_GELU_ERF), lp.fc2[0], lp.fc2[1], D)
+        hip.call("nova_row_norm", h.data_ptr(), xq.data_ptr(), lp.n2[0], lp.n2[1], None, 0, -1, -1, -1, xq.data_ptr(), None, S * n,
+                 D, 1e-5, code, st())
+        return xq
 
     def timestep_table(self, timesteps):
         """temb[i] = timestep_proj(freq_embed(t_i)) for every diffusion step (diffusion_mlp.py:65-73)."""
@@ -296,7 +339,6 @@ class NovaEngine(object):
         m.mask_embed.pred_ids = order.unsqueeze(-1)
         noise_fn = inputs.get("noise_fn", None)  # test hook: replay recorded per-step noise
         noise = torch.empty(B, C, H, W, dtype=_F32, device=rng_dev)
-        srow = (torch.arange(S, device=dev, dtype=torch.int64) * L2 + Nv)[:, None]
         done = 0
         for i, n in enumerate(num_preds):
             scaler.decay_guidance_scale((i + 1) / len(num_preds))
@@ -323,10 +365,11 @@ class NovaEngine(object):
             self._sequence(x2, x1, L1, z0, N, None, S, B, Nv, N)
             if done:
                 hip.call("nova_scatter_tokens", x1.data_ptr(), prev_ids.data_ptr(), x2.data_ptr(), S, B, Nv, N, done, D, code, st())
-            self._blocks(self.enc2, x2, S, L2, rope_i, 1, ws)
+            if self.enc2_head is not None:
+                self._blocks(self.enc2_head, x2, S, L2, rope_i, 1, ws)
+            y = self._last_block_rows(x2, S, B, L2, Nv, n, pred_ids, pos_img, inv_freq, rope_i, hd, ws)
             # final LN only on the rows predicted now, then the condition projection (time term added per step)
-            rows = (srow + torch.cat([pred_ids] * (S // B))).to(torch.int32).reshape(-1).contiguous()
-            zc = self._norm_rows(x2, self.inorm, gather=rows)
+            zc = self._norm_rows(y, self.inorm)
             w1, b1, w2, b2 = self.dec.time[1]
             zc = self._gemm(self._gemm(zc, w1, b1, D, hip.ACT_SILU), w2, b2, D)
             # noise for this step (RNG contract: one normal_ [B,C,H,W] per AR step, transformer_3d.py:131)

@@ -52,6 +52,7 @@ class Decoder(ctypes.Structure):
 SIGNATURES = {
     "nova_gemm_bias_act": [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
     "nova_qkv_rope": [c_void_p] * 5 + [c_int] * 6 + [c_void_p],
+    "nova_qkv_rope_cols": [c_void_p] * 5 + [c_int] * 8 + [c_void_p],
     "nova_rope_table": [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p],
     "nova_attn_fwd": [c_void_p] * 4 + [c_int] * 5 + [c_long] * 3 + [c_float, c_int, c_void_p],
     "nova_row_norm": [c_void_p] * 5 + [c_long] + [c_int] * 3 + [c_void_p, c_void_p, c_long, c_int, c_float, c_int, c_void_p],
