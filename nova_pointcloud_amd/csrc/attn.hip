@@ -29,6 +29,10 @@ constexpr int A_KV = 64;             // keys per tile
 constexpr int A_ROWB = 128;          // bytes per K/V row (64 x bf16)
 constexpr int A_TILE = A_KV * A_ROWB;  // 8 KiB
 
+// q arrives scaled by (softmax scale * log2 e) - folded into the fused QKV GEMM epilogue by the block composite, or
+// applied at load (c != 1) for generic callers - and the running max is carried as the C operand of the first
+// QK^T MFMA (a 16-register block holding -m), so the softmax needs no multiply-subtract per score: p = exp2(acc).
+// The block is rewritten only when the deferred-rescale branch fires.
 __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                       const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int Lq,
                                                       int Lk, long q_rs, long kv_rs, long o_rs, float c, int heads,
@@ -54,6 +58,12 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
     const bf16_t* qp = qb + (size_t)qrow * q_rs + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf8v*>(qp + 16 * ks);
+    if (c != 1.0f) {  // q not pre-scaled by the producer (generic nova_attn_fwd callers)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (__bf16)((float)qf[ks][j] * c);
+    }
   }
 
   // staging: wave w moves LDS-DMA pieces 2w, 2w+1 (8 rows x 128 B) of the K tile and of the V tile
@@ -75,7 +85,10 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
   f16v ot[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
-  float m_run = NEG_INF, l_run = 0.f;
+  float m_run = 0.f, l_run = 0.f;
+  f16v negm;  // -m_run replicated: the accumulator input of every tile's first MFMA
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 
   // per-lane constants of the transposing V read: lane 4*qr + p of each 16-lane group supplies
   // the address of row key0 + qr, columns dv0 + 4p .. 4p+3
@@ -91,7 +104,6 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
 
     // ---- S^T[key][q] for the two 32-key blocks
     f16v st[2];
-    const f16v zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int row = kb * 32 + r;
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
       for (int ks = 0; ks < 4; ++ks) {
         const int phys = (2 * ks + hh) ^ ((row >> 1) & 7);
         const bf8v kf = *reinterpret_cast<const bf8v*>(tk + row * A_ROWB + phys * 16);
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? zero16 : st[kb], 0, 0, 0);
+        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : st[kb], 0, 0, 0);
       }
     }
     if (kt == nkt - 1 && (Lk & (A_KV - 1)) != 0) {  // ragged last tile: keys >= Lk contribute nothing
@@ -122,15 +134,22 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
     // deferred rescale: the running max (and with it O, l) is only moved when some query of the wave saw its
     // max grow by more than 2^8 in the exp2 domain; until then p <= 2^8, exact in f32 accumulation and with
     // unchanged relative precision in bf16. The decision is wave-uniform; both lanes of a query agree on m.
-    const float m_new = fmaxf(m_run, mx);
-    if (__any((m_new - m_run) * c > 8.0f)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
+    // st already holds s*c - m_run (c folded into q, -m_run carried in by the first MFMA): mx is the growth of the
+    // running max in the exp2 domain. Deferred rescale: O, l and the carried max only move when some query of the
+    // wave grew by more than 2^8 (always on the first tile); until then p <= 2^8, exact in the f32 accumulators and
+    // with unchanged relative precision in bf16. The decision is wave-uniform; both lanes of a query agree on m.
+    if (kt == 0 || __any(mx > 8.0f)) {
+      const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+      if (kt != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        l_run *= alpha;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+        for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+      }
+      m_run += delta;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { st[0][i] -= delta; st[1][i] -= delta; negm[i] = -m_run; }
     }
-    const float mc = m_run * c;
     float psum = 0.f;
     bf8v pb[2][2];
 #pragma unroll
@@ -140,8 +159,8 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
         u4v packed;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // two probabilities -> one v_cvt_pk_bf16_f32
-          const float p0 = __builtin_amdgcn_exp2f(st[kb][8 * s2 + 2 * j] * c - mc);
-          const float p1 = __builtin_amdgcn_exp2f(st[kb][8 * s2 + 2 * j + 1] * c - mc);
+          const float p0 = __builtin_amdgcn_exp2f(st[kb][8 * s2 + 2 * j]);
+          const float p1 = __builtin_amdgcn_exp2f(st[kb][8 * s2 + 2 * j + 1]);
           psum += p0 + p1;
           const bf2v h = __builtin_convertvector(f2v{p0, p1}, bf2v);
           packed[j] = __builtin_bit_cast(uint32_t, h);
@@ -309,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_f32_hd64(const float* __restrict__ q
 }
 
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
-             long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st) {
+             long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st, bool q_prescaled) {
   if (S <= 0 || Lq <= 0) return 0;
   if (hd != 64) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64)", hd);
   if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
@@ -323,7 +342,7 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (dtype == NOVA_BF16) {
     const int nq = (Lq + 127) / 128;
     hipLaunchKernelGGL(attn_bf16_hd64, dim3((unsigned)((long)nq * heads * S)), block, 0, st, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, c, heads, nq);
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, q_prescaled ? 1.0f : c, heads, nq);
   } else {
     hipLaunchKernelGGL(attn_f32_hd64, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v,
                        (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);

@@ -220,9 +220,12 @@ int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, 
   const char* qkv = static_cast<const char*>(ws_qkv);
   for (int i = 0; i < nblocks; ++i) {
     const nova_vit_block& b = blocks[i];
-    NOVA_TRY(gemm_qkv_rope(x, b.qkv_w, b.qkv_b, rope, ws_qkv, S, L, D, heads, rope_batch, dtype, st));
+    // bf16: the softmax scale (in the exp2 domain) is folded into q by the QKV epilogue, before the bf16 rounding
+    const bool pre = dtype == NOVA_BF16;
+    NOVA_TRY(gemm_qkv_rope(x, b.qkv_w, b.qkv_b, rope, ws_qkv, S, L, D, heads, rope_batch, dtype, st,
+                           pre ? scale * 1.4426950408889634f : 1.0f));
     NOVA_TRY(attn_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, ws_a, S, heads, L, L, hd, 3L * D, 3L * D, D,
-                      scale, dtype, st));
+                      scale, dtype, st, pre));
     NOVA_TRY(gemm_bias_act(ws_a, b.proj_w, b.proj_b, ws_b, M, D, D, NOVA_ACT_NONE, dtype, st));
     RowNormArgs n1{ws_b, x, b.norm1_w, b.norm1_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
     NOVA_TRY(row_norm(n1, dtype, st));

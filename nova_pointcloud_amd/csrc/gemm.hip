@@ -30,6 +30,8 @@ struct GemmEpi {
   int rope_batch;        // table batch count; sequence s uses table s % rope_batch
   int hd;                // head dim
   int rope_cols;         // columns [0, rope_cols) are rotated (q and k thirds of the fused QKV)
+  float q_scale;         // columns [0, q_cols) are multiplied by this after rotation (softmax scale folded into q)
+  int q_cols;
 };
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU = 2, EPI_ROPE = 3 };
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
           v[2] = cs[nf][2] * x2 - cs[nf][3] * x3;
           v[3] = cs[nf][3] * x2 + cs[nf][2] * x3;
         }
+        if (n0 < e.q_cols) v = v * e.q_scale;  // tile-uniform like `rot`
       }
       if constexpr (sizeof(T) == 2) {
         u2v o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 
 // gemm256.hip: 256x256 ping-pong kernel for large M
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
-                   const float* rope, int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st);
+                   const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
+                   hipStream_t st);
 
 void gemm256_set_variant(int v);
 static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
@@ -201,10 +205,10 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
   if (M <= 0) return 0;
   if (N % BN != 0 || K % kelems != 0 || K <= 0)
     return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
-  const bool can256 = N % 256 == 0 && (epi != EPI_ROPE || e.rope_cols % 256 == 0);  // rotation is decided per tile
+  const bool can256 = N % 256 == 0 && (epi != EPI_ROPE || (e.rope_cols % 256 == 0 && e.q_cols % 256 == 0));  // rotation is decided per tile
   if (g_force_tile == 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
   if (can256 && (g_force_tile == 256 || (g_force_tile == 0 && M >= 4096)))
-    return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols,
+    return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols, e.q_scale, e.q_cols,
                           sizeof(T) == 2 ? NOVA_BF16 : NOVA_F32, st);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(ntm * ntn), block(256);
@@ -224,19 +228,19 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
 
 int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                   int dtype, hipStream_t st) {
-  GemmEpi e{bias, nullptr, 1, 1, 2, 0};
+  GemmEpi e{bias, nullptr, 1, 1, 2, 0, 1.0f, 0};
   if (act < 0 || act > 2) return set_error(NOVA_ERR_ARG, "gemm: unknown activation %d", act);
   return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(A, W, out, M, N, K, act, e, st)
                             : launch_gemm<float>(A, W, out, M, N, K, act, e, st);
 }
 
 int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L,
-                  int D, int heads, int rope_batch, int dtype, hipStream_t st) {
+                  int D, int heads, int rope_batch, int dtype, hipStream_t st, float q_scale) {
   const int hd = D / heads;
   if (heads <= 0 || D % heads != 0 || hd % 4 != 0) return set_error(NOVA_ERR_SHAPE, "qkv_rope: bad heads/D");
-  const int epi = rope ? EPI_ROPE : EPI_NONE;
+  const int epi = (rope || q_scale != 1.0f) ? EPI_ROPE : EPI_NONE;
   if (rope && rope_batch <= 0) return set_error(NOVA_ERR_ARG, "qkv_rope: rope_batch must be > 0");
-  GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, 2 * D};
+  GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, rope ? 2 * D : 0, q_scale, q_scale != 1.0f ? D : 0};
   return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st)
                             : launch_gemm<float>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st);
 }
@@ -244,7 +248,7 @@ int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const floa
 int gemm_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
                    int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st) {
   if (rope && rope_batch <= 0) return set_error(NOVA_ERR_ARG, "rope_cols: rope_batch must be > 0");
-  GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, rope_cols};
+  GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, rope_cols, 1.0f, 0};
   const int epi = rope ? EPI_ROPE : EPI_NONE;
   return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(x, W, out, M, N, K, epi, e, st) : launch_gemm<float>(x, W, out, M, N, K, epi, e, st);
 }

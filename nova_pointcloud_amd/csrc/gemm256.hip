@@ -38,6 +38,8 @@ struct GemmEpi256 {
   const float* bias;
   const float* rope;
   int L, rope_batch, hd, rope_cols;
+  float q_scale;
+  int q_cols;
 };
 
 enum { E_NONE = 0, E_GELU = 1, E_SILU = 2, E_ROPE = 3 };
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
           v[2] = cs[nf][2] * x2 - cs[nf][3] * x3;
           v[3] = cs[nf][3] * x2 + cs[nf][2] * x3;
         }
+        if (n0 < e.q_cols) v = v * e.q_scale;
       }
       if constexpr (sizeof(T) == 2) {
         pk[nf] = u2v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
@@ -311,8 +314,9 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
 // Entry used by gemm.hip's dispatcher. Preconditions (checked by the caller): N % 256 == 0,
 // K % (128 / sizeof(T)) == 0, K > 0, M > 0.
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
-                   const float* rope, int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st) {
-  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols};
+                   const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
+                   hipStream_t st) {
+  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols};
   return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st) : launch256<float>(A, W, C, M, N, K, epi, e, st);
 }
 

@@ -24,7 +24,7 @@ struct ProfScope {
 int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                   int dtype, hipStream_t st);
 int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L,
-                  int D, int heads, int rope_batch, int dtype, hipStream_t st);
+                  int D, int heads, int rope_batch, int dtype, hipStream_t st, float q_scale = 1.0f);
 
 int gemm_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
                    int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st);
@@ -32,7 +32,8 @@ void gemm_force_tile(int tile);
 
 // ---- attn.hip
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
-             long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st);
+             long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st,
+             bool q_prescaled = false);
 
 // ---- rowops.hip
 struct RowNormArgs {
