@@ -37,6 +37,7 @@ WORKLOADS = {
     "d48w1024_2048pts_b32": (1024, 16, 32, 64, 32),
     "d48w768_1024pts_b8": (768, 12, 32, 32, 8),
     "d48w768_256pts_b1": (768, 12, 16, 16, 1),
+    "d48w1536_2048pts_b32": (1536, 16, 32, 64, 32),  # configs[4] architecture (head_dim 96) in bf16
 }
 
 
@@ -188,7 +189,8 @@ def main():
         mfma = {k: v for k, v in fams.items() if k != "row_norm"}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         rec = {
-            "metric": "generated points/sec/node, NOVA-d48w1024 @2048 pts, 64-step sample",
+            "metric": "generated points/sec/node, NOVA-d48w1024 @2048 pts, 64-step sample" if args.workload.startswith("d48w1024")
+            else f"generated points/sec/node, {args.workload}",
             "value": round(value, 2), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

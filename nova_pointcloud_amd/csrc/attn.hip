@@ -15,6 +15,8 @@
 //   MFMA (no LDS round trip); V^T fragments come from the row-major V tile through the hardware
 //   transposing read ds_read_b64_tr_b16. Rescale factors and 1/l are lane-local as well.
 // f32 kernel (parity mode): same skeleton on v_mfma_f32_32x32x2_f32 (exact f32), 32-key tiles.
+// head_dim 64 (d48w768 / d48w1024) and 96 (d48w1536: the K/V tile is staged as a 64-wide image plus a 32-wide
+// image so every LDS-DMA piece stays row-aligned and both images keep conflict-free read patterns).
 #include "common.h"
 #include "nova_internal.h"
 
@@ -23,68 +25,80 @@ namespace nova {
 constexpr float NEG_INF = -__builtin_huge_valf();
 
 // ------------------------------------------------------------------------------------------
-// bf16, head_dim 64
+// bf16, head_dim HD in {64, 96}
 // ------------------------------------------------------------------------------------------
-constexpr int A_KV = 64;             // keys per tile
-constexpr int A_ROWB = 128;          // bytes per K/V row (64 x bf16)
-constexpr int A_TILE = A_KV * A_ROWB;  // 8 KiB
+constexpr int A_KV = 64;                 // keys per tile
+constexpr int A_T64 = A_KV * 128;        // 64-wide image: 128-byte rows, 8 KiB
+constexpr int A_T32 = A_KV * 64;         // 32-wide image (HD = 96 only): 64-byte rows, 4 KiB
 
 // q arrives scaled by (softmax scale * log2 e) - folded into the fused QKV GEMM epilogue by the block composite, or
 // applied at load (c != 1) for generic callers - and the running max is carried as the C operand of the first
 // QK^T MFMA (a 16-register block holding -m), so the softmax needs no multiply-subtract per score: p = exp2(acc).
 // The block is rewritten only when the deferred-rescale branch fires.
-__global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                      const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int Lq,
-                                                      int Lk, long q_rs, long kv_rs, long o_rs, float c, int heads,
-                                                      int nq) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * A_TILE];  // [buf][K|V]
+template <int HD>
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                    const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+                                                                    int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
+                                                                    int heads, int nq) {
+  constexpr int NKS = HD / 16, NDV = HD / 32;
+  constexpr int BUF = 2 * A_T64 + (HD == 96 ? 2 * A_T32 : 0);  // [K64 | V64 | K32 | V32]
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   // XCD-aware order: all query tiles of one (sequence, head) are consecutive in the remapped list, so they
-  // run on one XCD and its K/V (2 * Lk * 128 B) is served from that XCD's L2 after the first tile.
+  // run on one XCD and its K/V is served from that XCD's L2 after the first tile.
   const int t = xcd_remap(blockIdx.x, gridDim.x);
   const int sh = t / nq, qt = t - sh * nq;
   const int head = sh % heads, s = sh / heads;
   const int q0 = qt * 128 + wid * 32;
 
-  const bf16_t* qb = q + (size_t)s * Lq * q_rs + head * 64;
-  const bf16_t* kb_ = k + (size_t)s * Lk * kv_rs + head * 64;
-  const bf16_t* vb_ = v + (size_t)s * Lk * kv_rs + head * 64;
+  const bf16_t* qb = q + (size_t)s * Lq * q_rs + head * HD;
+  const bf16_t* kb_ = k + (size_t)s * Lk * kv_rs + head * HD;
+  const bf16_t* vb_ = v + (size_t)s * Lk * kv_rs + head * HD;
 
   // Q fragments: B operand of S^T = K Q^T; lane (r, hh) holds Q[q0 + r][16 ks + 8 hh + 0..7]
-  bf8v qf[4];
+  bf8v qf[NKS];
   {
     const int qrow = min(q0 + r, Lq - 1);
     const bf16_t* qp = qb + (size_t)qrow * q_rs + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf8v*>(qp + 16 * ks);
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf8v*>(qp + 16 * ks);
     if (c != 1.0f) {  // q not pre-scaled by the producer (generic nova_attn_fwd callers)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
         for (int j = 0; j < 8; ++j) qf[ks][j] = (__bf16)((float)qf[ks][j] * c);
     }
   }
 
-  // staging: wave w moves LDS-DMA pieces 2w, 2w+1 (8 rows x 128 B) of the K tile and of the V tile
-  const int rr = lane >> 3, cp = lane & 7;
+  // staging: wave w moves LDS-DMA pieces 2w, 2w+1 (8 rows x 128 B) of the 64-wide K and V images and, for
+  // HD = 96, piece w (16 rows x 64 B) of the 32-wide images
   auto stage = [&](int buf, int kt) {
-    char* lk = smem + buf * 2 * A_TILE;
-    char* lv = lk + A_TILE;
+    char* lk = smem + buf * BUF;
+    char* lv = lk + A_T64;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int piece = wid * 2 + i, row = piece * 8 + rr;
+      const int piece = wid * 2 + i, row = piece * 8 + (lane >> 3), cp = lane & 7;
       const int key = min(kt * A_KV + row, Lk - 1);
       const int ck = cp ^ ((row >> 1) & 7);           // K image: conflict-free ds_read_b128 by row
       const int cv = cp ^ (((row >> 1) & 1) << 2);    // V image: conflict-free ds_read_b64_tr_b16
       __builtin_amdgcn_global_load_lds(kb_ + (size_t)key * kv_rs + ck * 8, NOVA_LDS_PTR(lk + piece * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(vb_ + (size_t)key * kv_rs + cv * 8, NOVA_LDS_PTR(lv + piece * 1024), 16, 0, 0);
     }
+    if constexpr (HD == 96) {
+      const int row = wid * 16 + (lane >> 2), cp = lane & 3;
+      const int key = min(kt * A_KV + row, Lk - 1);
+      const int ck = cp ^ ((row >> 2) & 3);           // 64-byte rows: 4 rows per bank row
+      __builtin_amdgcn_global_load_lds(kb_ + (size_t)key * kv_rs + 64 + ck * 8, NOVA_LDS_PTR(lk + 2 * A_T64 + wid * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vb_ + (size_t)key * kv_rs + 64 + cp * 8, NOVA_LDS_PTR(lk + 2 * A_T64 + A_T32 + wid * 1024), 16, 0, 0);
+    }
   };
 
-  f16v ot[2];
+  f16v ot[NDV];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
+  for (int d = 0; d < NDV; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
   float m_run = 0.f, l_run = 0.f;
   f16v negm;  // -m_run replicated: the accumulator input of every tile's first MFMA
 #pragma unroll
@@ -99,18 +113,21 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
-    const char* tk = smem + (kt & 1) * 2 * A_TILE;
-    const char* tv = tk + A_TILE;
+    const char* tk = smem + (kt & 1) * BUF;
+    const char* tv = tk + A_T64;
+    const char* tk32 = tk + 2 * A_T64;
+    const char* tv32 = tk32 + A_T32;
 
-    // ---- S^T[key][q] for the two 32-key blocks
+    // ---- S^T[key][q] - m for the two 32-key blocks
     f16v st[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int row = kb * 32 + r;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int phys = (2 * ks + hh) ^ ((row >> 1) & 7);
-        const bf8v kf = *reinterpret_cast<const bf8v*>(tk + row * A_ROWB + phys * 16);
+      for (int ks = 0; ks < NKS; ++ks) {
+        bf8v kf;
+        if (ks < 4) kf = *reinterpret_cast<const bf8v*>(tk + row * 128 + (((2 * ks + hh) ^ ((row >> 1) & 7)) << 4));
+        else kf = *reinterpret_cast<const bf8v*>(tk32 + row * 64 + (((2 * (ks - 4) + hh) ^ ((row >> 2) & 3)) << 4));
         st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : st[kb], 0, 0, 0);
       }
     }
@@ -131,9 +148,6 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
 #pragma unroll
     for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    // deferred rescale: the running max (and with it O, l) is only moved when some query of the wave saw its
-    // max grow by more than 2^8 in the exp2 domain; until then p <= 2^8, exact in f32 accumulation and with
-    // unchanged relative precision in bf16. The decision is wave-uniform; both lanes of a query agree on m.
     // st already holds s*c - m_run (c folded into q, -m_run carried in by the first MFMA): mx is the growth of the
     // running max in the exp2 domain. Deferred rescale: O, l and the carried max only move when some query of the
     // wave grew by more than 2^8 (always on the first tile); until then p <= 2^8, exact in the f32 accumulators and
@@ -144,7 +158,9 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
         const float alpha = __builtin_amdgcn_exp2f(-delta);
         l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+        for (int d = 0; d < NDV; ++d)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
       }
       m_run += delta;
 #pragma unroll
@@ -171,8 +187,8 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
 
     // ---- O^T[dv][q] += V^T[dv][key] P^T[key][q]
 #pragma unroll
-    for (int dvb = 0; dvb < 2; ++dvb) {
-      const int col = dvb * 32 + 16 * t_gp + 4 * t_p;
+    for (int dvb = 0; dvb < NDV; ++dvb) {
+      const int col = (dvb & 1) * 32 + 16 * t_gp + 4 * t_p;  // column inside its image (64-wide: dvb 0,1; 32-wide: dvb 2)
       const int chunk = col >> 3, within = (t_p & 1) * 8;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -180,8 +196,14 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
         for (int s2 = 0; s2 < 2; ++s2) {
           const int row0 = kb * 32 + 16 * s2 + 4 * hh + t_qr;
           const int row1 = row0 + 8;
-          const char* a0 = tv + row0 * A_ROWB + ((chunk ^ (((row0 >> 1) & 1) << 2)) * 16) + within;
-          const char* a1 = tv + row1 * A_ROWB + ((chunk ^ (((row1 >> 1) & 1) << 2)) * 16) + within;
+          const char *a0, *a1;
+          if (dvb < 2) {
+            a0 = tv + row0 * 128 + ((chunk ^ (((row0 >> 1) & 1) << 2)) << 4) + within;
+            a1 = tv + row1 * 128 + ((chunk ^ (((row1 >> 1) & 1) << 2)) << 4) + within;
+          } else {  // 4 consecutive 64-byte rows per 32-lane half = one 256-byte bank row: conflict-free as is
+            a0 = tv32 + row0 * 64 + (chunk << 4) + within;
+            a1 = tv32 + row1 * 64 + (chunk << 4) + within;
+          }
           const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
           const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a1);
           const bf8v vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -195,9 +217,9 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + r;
   if (qrow < Lq) {
-    bf16_t* op = o + ((size_t)s * Lq + qrow) * o_rs + head * 64;
+    bf16_t* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD;
 #pragma unroll
-    for (int dvb = 0; dvb < 2; ++dvb)
+    for (int dvb = 0; dvb < NDV; ++dvb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int dv = dvb * 32 + 8 * g + 4 * hh;
@@ -209,52 +231,57 @@ __global__ __launch_bounds__(256, 3) void attn_bf16_hd64(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------
-// f32 (parity mode), head_dim 64, 32-key tiles, exact-f32 MFMA
+// f32 (parity mode), head_dim HD in {64, 96}, 32-key tiles, exact-f32 MFMA
 // ------------------------------------------------------------------------------------------
 constexpr int F_KV = 32;
-constexpr int F_ROWB = 256;            // 64 x f32
-constexpr int F_TILE = F_KV * F_ROWB;  // 8 KiB
 
-__global__ __launch_bounds__(256) void attn_f32_hd64(const float* __restrict__ q, const float* __restrict__ k,
-                                                     const float* __restrict__ v, float* __restrict__ o, int Lq,
-                                                     int Lk, long q_rs, long kv_rs, long o_rs, float c) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * F_TILE];
+template <int HD>
+__global__ __launch_bounds__(256) void attn_f32(const float* __restrict__ q, const float* __restrict__ k,
+                                                const float* __restrict__ v, float* __restrict__ o, int Lq, int Lk,
+                                                long q_rs, long kv_rs, long o_rs, float c) {
+  constexpr int ROWB = HD * 4, TILE = F_KV * ROWB, NCS = HD / 8, NDV = HD / 32, PPW = TILE / 4096;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int head = blockIdx.y, s = blockIdx.z;
   const int q0 = blockIdx.x * 128 + wid * 32;
 
-  const float* qb = q + (size_t)s * Lq * q_rs + head * 64;
-  const float* kb_ = k + (size_t)s * Lk * kv_rs + head * 64;
-  const float* vb_ = v + (size_t)s * Lk * kv_rs + head * 64;
+  const float* qb = q + (size_t)s * Lq * q_rs + head * HD;
+  const float* kb_ = k + (size_t)s * Lk * kv_rs + head * HD;
+  const float* vb_ = v + (size_t)s * Lk * kv_rs + head * HD;
 
   // lane (r, hh) holds Q[q0 + r][4 (2 cs + hh) + j]; MFMA step (cs, j) contracts the k pair
   // {4(2cs)+j, 4(2cs+1)+j} (any consistent order is a valid contraction)
-  f4v qf[8];
+  f4v qf[NCS];
   {
     const int qrow = min(q0 + r, Lq - 1);
     const float* qp = qb + (size_t)qrow * q_rs + 4 * hh;
 #pragma unroll
-    for (int cs = 0; cs < 8; ++cs) qf[cs] = *reinterpret_cast<const f4v*>(qp + 8 * cs);
+    for (int cs = 0; cs < NCS; ++cs) qf[cs] = *reinterpret_cast<const f4v*>(qp + 8 * cs);
   }
 
-  const int rr = lane >> 4, cp = lane & 15;
+  // K image: 16-byte chunk XOR-swizzled by row for HD = 64 (256-byte rows = one bank row); HD = 96 is left
+  // unswizzled (bank conflicts only cost time, and this is the parity path)
   auto stage = [&](int buf, int kt) {
-    char* lk = smem + buf * 2 * F_TILE;
-    char* lv = lk + F_TILE;
+    char* lk = smem + buf * 2 * TILE;
+    char* lv = lk + TILE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = wid * 2 + i, row = piece * 4 + rr;
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wid * PPW + i;
+      const int lin = piece * 64 + lane;           // 16-byte chunk index inside the tile (lane-linear LDS image)
+      const int row = lin / (ROWB / 16), cp = lin % (ROWB / 16);
       const int key = min(kt * F_KV + row, Lk - 1);
-      const int ck = cp ^ (row & 15);
+      const int ck = HD == 64 ? (cp ^ (row & 15)) : cp;
       __builtin_amdgcn_global_load_lds(kb_ + (size_t)key * kv_rs + ck * 4, NOVA_LDS_PTR(lk + piece * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(vb_ + (size_t)key * kv_rs + cp * 4, NOVA_LDS_PTR(lv + piece * 1024), 16, 0, 0);
     }
   };
 
-  f16v ot[2];
+  f16v ot[NDV];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { ot[0][i] = 0.f; ot[1][i] = 0.f; }
+  for (int d = 0; d < NDV; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ot[d][i] = 0.f;
   float m_run = NEG_INF, l_run = 0.f;
 
   const int nkt = (Lk + F_KV - 1) / F_KV;
@@ -262,16 +289,16 @@ __global__ __launch_bounds__(256) void attn_f32_hd64(const float* __restrict__ q
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
-    const char* tk = smem + (kt & 1) * 2 * F_TILE;
-    const float* tv = reinterpret_cast<const float*>(tk + F_TILE);
+    const char* tk = smem + (kt & 1) * 2 * TILE;
+    const float* tv = reinterpret_cast<const float*>(tk + TILE);
 
     f16v st;
 #pragma unroll
     for (int i = 0; i < 16; ++i) st[i] = 0.f;
 #pragma unroll
-    for (int cs = 0; cs < 8; ++cs) {
-      const int phys = (2 * cs + hh) ^ (r & 15);
-      const f4v kf = *reinterpret_cast<const f4v*>(tk + r * F_ROWB + phys * 16);
+    for (int cs = 0; cs < NCS; ++cs) {
+      const int phys = HD == 64 ? ((2 * cs + hh) ^ (r & 15)) : (2 * cs + hh);
+      const f4v kf = *reinterpret_cast<const f4v*>(tk + r * ROWB + phys * 16);
 #pragma unroll
       for (int j = 0; j < 4; ++j) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[cs][j], st, 0, 0, 0);
     }
@@ -299,14 +326,16 @@ __global__ __launch_bounds__(256) void attn_f32_hd64(const float* __restrict__ q
     }
     l_run = l_run * alpha + psum;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { ot[0][i] *= alpha; ot[1][i] *= alpha; }
+    for (int d = 0; d < NDV; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ot[d][i] *= alpha;
 
 #pragma unroll
-    for (int dvb = 0; dvb < 2; ++dvb)
+    for (int dvb = 0; dvb < NDV; ++dvb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const float vv = tv[key * 64 + dvb * 32 + r];
+        const float vv = tv[key * HD + dvb * 32 + r];
         ot[dvb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, st[i], ot[dvb], 0, 0, 0);
       }
   }
@@ -315,9 +344,9 @@ __global__ __launch_bounds__(256) void attn_f32_hd64(const float* __restrict__ q
   const float inv = 1.0f / l_tot;
   const int qrow = q0 + r;
   if (qrow < Lq) {
-    float* op = o + ((size_t)s * Lq + qrow) * o_rs + head * 64;
+    float* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD;
 #pragma unroll
-    for (int dvb = 0; dvb < 2; ++dvb)
+    for (int dvb = 0; dvb < NDV; ++dvb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int dv = dvb * 32 + 8 * g + 4 * hh;
@@ -330,22 +359,24 @@ __global__ __launch_bounds__(256) void attn_f32_hd64(const float* __restrict__ q
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
              long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st, bool q_prescaled) {
   if (S <= 0 || Lq <= 0) return 0;
-  if (hd != 64) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64)", hd);
+  if (hd != 64 && hd != 96) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64 and 96)", hd);
   if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
   const int align = dtype == NOVA_BF16 ? 8 : 4;  // 16-byte row alignment for the vector loads
   if (q_rs % align || kv_rs % align || o_rs % align) return set_error(NOVA_ERR_SHAPE, "attn_fwd: row strides must be 16-byte multiples");
-  if (S > 65535 || heads > 65535 || (long)((Lq + 127) / 128) * heads * S > 0x7fffffffL)
-    return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
+  const int nq = (Lq + 127) / 128;
+  if (S > 65535 || heads > 65535 || (long)nq * heads * S > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
   const float c = scale * 1.4426950408889634f;
-  dim3 grid((Lq + 127) / 128, heads, S), block(256);
+  dim3 grid(nq, heads, S), block(256), grid1((unsigned)((long)nq * heads * S));
   ProfScope prof(PROF_ATTN, 4.0 * S * heads * (double)Lq * Lk * hd, st);
   if (dtype == NOVA_BF16) {
-    const int nq = (Lq + 127) / 128;
-    hipLaunchKernelGGL(attn_bf16_hd64, dim3((unsigned)((long)nq * heads * S)), block, 0, st, (const bf16_t*)q,
-                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, q_prescaled ? 1.0f : c, heads, nq);
+    const float cl = q_prescaled ? 1.0f : c;
+    const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v;
+    if (hd == 64) hipLaunchKernelGGL(attn_bf16<64>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq);
+    else hipLaunchKernelGGL(attn_bf16<96>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq);
   } else {
-    hipLaunchKernelGGL(attn_f32_hd64, grid, block, 0, st, (const float*)q, (const float*)k, (const float*)v,
-                       (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);
+    const float *qq = (const float*)q, *kk = (const float*)k, *vv = (const float*)v;
+    if (hd == 64) hipLaunchKernelGGL(attn_f32<64>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);
+    else hipLaunchKernelGGL(attn_f32<96>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);
   }
   return check_launch("attn_fwd");
 }

@@ -183,3 +183,37 @@ def test_full_size_pipeline_properties(hip):
     single = run([1])
     assert rms_rel(single, a[1:2]) < 2e-2  # bf16: tile shapes (hence rounding order inside row-independent kernels) are unchanged
     assert (a[0] - a[1]).abs().max() > 1e-3
+
+
+def test_head_dim_96_model_matches_oracle(hip):
+    """d48w1536's head_dim (96: RoPE split 12/42/42, 3 value blocks) on a narrow stand-in (D = 384, 4 heads):
+    f32 pipeline on the GPU against the oracle (pinned on the 64-wide goldens; the code path is dimension generic)."""
+    from diffnext.models.transformers import transformer_nova as TN
+
+    D, heads = 384, 4
+    TN.VIDEO_ENCODERS.register("vit_d1w384", TN._vit, depth=1, embed_dim=D, num_heads=heads)
+    TN.IMAGE_ENCODERS.register("vit_d2w384", TN._vit, depth=2, embed_dim=D, num_heads=heads)
+    TN.IMAGE_DECODERS.register("mlp_d1w384", TN._mlp, depth=1, embed_dim=D)
+    torch.manual_seed(11)
+    model = TN.NOVATransformer3DModel(image_dim=3, image_size=(8 * 16, 12 * 16), image_stride=16, text_token_dim=64,
+                                      text_token_len=8, image_base_size=[8, 12], video_base_size=[1, 4, 6],
+                                      rotary_pos_embed=True, arch=("vit_d1w384", "vit_d2w384", "mlp_d1w384")).eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("bias"):
+                p_.add_(torch.randn_like(p_) * 0.05)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randn(5, 64, generator=g) * 0.5, torch.randn(8, 64, generator=g) * 0.5]
+    pipe = NOVAPipeline(transformer=model.cuda(), scheduler=FlowMatchEulerDiscreteScheduler())
+    out = pipe(prompt_embeds=[p.cuda() for p in prompts], num_inference_steps=4, num_diffusion_steps=3, guidance_scale=4.0,
+               generator=torch.Generator().manual_seed(5), output_type="latent", disable_progress_bar=True).frames
+    cfg = O.make_config(3, (8, 12), 1, D, heads, 1, 2, 1, 8, rotary=True)
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 8)
+    ref = O.generate(sd, cfg, prompt, O.cosine_schedule(96, 4), num_diffusion_steps=3, guidance_scale=4.0,
+                     generator=torch.Generator().manual_seed(5))
+    assert rel(out, ref) < 1e-3
+    x16 = NOVAPipeline(transformer=model.to(torch.bfloat16), scheduler=FlowMatchEulerDiscreteScheduler())(
+        prompt_embeds=[p.cuda() for p in prompts], num_inference_steps=4, num_diffusion_steps=3, guidance_scale=4.0,
+        generator=torch.Generator().manual_seed(5), output_type="latent", disable_progress_bar=True).frames
+    assert torch.isfinite(x16.float()).all()

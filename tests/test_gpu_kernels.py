@@ -86,8 +86,9 @@ def grid_pos(h, w):
     return torch.stack([t, hh, ww], -1).to(DEV)
 
 
-def test_rope_table(hip):
-    hd, pad, nb = 64, 5, 3
+@pytest.mark.parametrize("hd", [64, 96])
+def test_rope_table(hip, hd):
+    pad, nb = 5, 3
     pos = grid_pos(6, 7)
     g = torch.Generator().manual_seed(0)
     ids = torch.stack([torch.randperm(42, generator=g)[:17] for _ in range(nb)]).to(DEV)
@@ -99,8 +100,9 @@ def test_rope_table(hip):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_qkv_rope(hip, dtype):
-    S, L, D, heads, nb = 4, 37, 128, 2, 2
+@pytest.mark.parametrize("D,heads", [(128, 2), (384, 4)])
+def test_qkv_rope(hip, dtype, D, heads):
+    S, L, nb = 4, 37, 2
     hd = D // heads
     x, w, b = rnd(S * L, D, dtype=dtype), rnd(3 * D, D, dtype=dtype, scale=D ** -0.5, seed=5), rnd(3 * D, seed=6)
     pos = grid_pos(8, 8)
@@ -121,9 +123,9 @@ def test_qkv_rope(hip, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hd", [64, 96])
 @pytest.mark.parametrize("S,heads,L", [(1, 1, 64), (2, 2, 128), (2, 3, 200), (1, 2, 333), (3, 1, 31), (1, 4, 769)])
-def test_attention(hip, dtype, S, heads, L):
-    hd = 64
+def test_attention(hip, dtype, hd, S, heads, L):
     D = heads * hd
     qkv = rnd(S * L, 3 * D, dtype=dtype, seed=7)
     out = hip.attn_fwd_packed(qkv, S, L, heads)
@@ -133,9 +135,10 @@ def test_attention(hip, dtype, S, heads, L):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_spiky_rows(hip, dtype):
+@pytest.mark.parametrize("hd", [64, 96])
+def test_attention_spiky_rows(hip, dtype, hd):
     """Force large running-max jumps late in the key stream (online-softmax rescale path)."""
-    S, heads, L, hd = 1, 1, 320, 64
+    S, heads, L = 1, 1, 320
     qkv = rnd(S * L, 3 * hd, dtype=dtype, seed=9)
     q = qkv[:, :hd].float()
     qkv[300, hd:2 * hd] = (q[5] * 4).to(dtype)   # key 300 aligned with query 5
