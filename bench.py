@@ -188,6 +188,17 @@ def main():
                     "unit": "GB/s" if k == "row_norm" else "TFLOP/s"} for k, (ms, wk, n) in prof.items() if n}
         mfma = {k: v for k, v in fams.items() if k != "row_norm"}
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
+        # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read from inside
+        # the process); the committed summary is for the largest launch of that kernel, so it is reported with its context.
+        traffic, traffic_note = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if dom == "attention" and args.workload == "d48w1024_2048pts_b32":
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_note = (f"PMC bytes of the {pmc['launch']} launch ({pmc['source']}); algorithmic bytes of that launch "
+                                f"{pmc['algorithmic_bytes_per_launch'] / 1e6:.1f} MB")
+        except (OSError, KeyError, ValueError):
+            pass
         rec = {
             "metric": "generated points/sec/node, NOVA-d48w1024 @2048 pts, 64-step sample" if args.workload.startswith("d48w1024")
             else f"generated points/sec/node, {args.workload}",
@@ -198,7 +209,7 @@ def main():
                        "diffusion_steps": args.diffusion_steps, "batch_per_gpu": B, "global_batch": world * B,
                        "guidance": "cfg 2-pass", "sharding": f"batch rows over {world} GPU(s), all_gather of points"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["rate"], "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(mfma[dom]["rate"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(mfma[dom]["rate"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": round(mfma[dom]["ms"] / mfma[dom]["launches"], 4),
                          "share_of_step_time": round(mfma[dom]["ms"] / 1e3 / elapsed, 3)},
             "end_to_end": {"tflops_per_gpu": round(e2e_tflops, 1), "frac_of_mfma_peak": round(e2e_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
