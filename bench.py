@@ -121,20 +121,30 @@ def main():
     ap.add_argument("--diffusion-steps", type=int, default=25)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-dry-run", action="store_true",
+                    help="rehearse the multi-process control flow on CPU (gloo, PyTorch module path, f32): not a measurement")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    dry = args.cpu_dry_run
+    if dry:
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    torch.set_num_threads(max(1, host_cores() // world))  # N ranks build N CPU-initialised copies of the weights
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from nova_pointcloud_amd import hip
     from nova_pointcloud_amd.sharding import gather_points
@@ -142,10 +152,11 @@ def main():
 
     width, heads, H, W, B = WORKLOADS[args.workload]
     B = args.batch or B
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if dry else (torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     pipe = build_pipeline(width, heads, H, W, dtype, device)
     prompts = synthetic_prompts(B, device, dtype, seed=1234 + rank)  # every rank generates its own shard
     gen = torch.Generator(device=device).manual_seed(rank)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
     N, Nv = H * W, (H // 2) * (W // 2)
 
     def step():
@@ -158,21 +169,25 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     for _ in range(args.warmup):
         pts = step()
     fence()
-    hip.prof_enable(True)
-    hip.prof_collect()
+    if not dry:
+        hip.prof_enable(True)
+        hip.prof_collect()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pts = step()
     fence()
     elapsed = time.perf_counter() - t0
-    prof = hip.prof_collect()
-    hip.prof_enable(False)
+    prof = {}
+    if not dry:
+        prof = hip.prof_collect()
+        hip.prof_enable(False)
     assert torch.isfinite(pts).all(), "non-finite points generated"
+    assert pts.shape[0] == world * B, "gathered point sets do not cover the global batch"
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -187,6 +202,12 @@ def main():
                     "rate": round(wk / ms / (1e6 if k == "row_norm" else 1e9), 2) if ms > 0 else 0.0,
                     "unit": "GB/s" if k == "row_norm" else "TFLOP/s"} for k, (ms, wk, n) in prof.items() if n}
         mfma = {k: v for k, v in fams.items() if k != "row_norm"}
+        if dry:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "points": list(pts.shape), "ms_per_step": round(elapsed / args.steps * 1e3, 2)}), flush=True)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read from inside
         # the process); the committed summary is for the largest launch of that kernel, so it is reported with its context.

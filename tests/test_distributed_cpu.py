@@ -72,3 +72,20 @@ def test_two_rank_sharded_generation_matches_per_shard_runs(ragged):
     want = torch.cat([_run_pipe(gold, shard_list(prompts, r, 2), seed=100 + r) for r in range(2)])
     assert got.shape == want.shape == (len(prompts), gold.meta["latent_h"] * gold.meta["latent_w"], 3)
     assert torch.equal(got, want)
+
+
+def test_bench_launch_contract_two_ranks_dry_run():
+    """The driver's N > 1 launch line, rehearsed on CPU (gloo): rendezvous, per-rank shard, gather, max-over-ranks timing."""
+    import json
+    import subprocess
+
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--cpu-dry-run", "--workload", "d48w768_256pts_b1", "--ar-steps", "2", "--diffusion-steps", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # exactly one JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["points"] == [2, 256, 3]
