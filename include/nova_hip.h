@@ -184,18 +184,32 @@ typedef struct {
   const float* head_b;
 } nova_decoder;
 
-/* All `steps` flow-matching Euler steps of Transformer3DModel.denoise (transformer_3d.py:102-113)
- * for the n tokens predicted in this AR step, launched back to back on `stream`:
+/* One sampler step, prepared on the host (float32): with v = CFG-combined head output,
+ *   x0 = clamp(kx*x + kv*v, +-clip) (clip <= 0: none);   x <- c0*x0 + cx*x + sigma*noise
+ * Flow-matching Euler (scheduling_cfm.py:134-136): kx=0, kv=1, clip=0, c0=sigma_{i+1}-sigma_i, cx=1, sigma=0.
+ * DDPM (scheduling_ddpm.py:236-316): kx, kv from prediction_type (:271-280), clip = clip_sample_range (:283-289),
+ * c0 / cx the posterior-mean coefficients (:293-298), sigma the posterior std (:303-312).
+ * guidance <= 1 disables CFG for that step (guidance_trunc, guidance_scaler.py:59-65). */
+typedef struct {
+  float guidance, kx, kv, clip, c0, cx, sigma;
+} nova_sampler_step;
+
+/* All `steps` sampler steps of Transformer3DModel.denoise (transformer_3d.py:102-113) for the n tokens predicted in
+ * this AR step, launched back to back on `stream`:
  *   zc    [S*n, D]   condition rows: condition_proj(LN(z)[pred_ids]) (time term NOT yet added)
  *   temb  [steps, D] timestep_proj(freq(t_i)) per step (diffusion_mlp.py:73)
  *   x     [B, n, P]  f32, in: noise rows, out: denoised patch vectors
- *   dt    [steps]    host array sigma_{i+1} - sigma_i (scheduling_cfm.py:134)
- *   guidance[steps]  host array; entry <= 1 disables CFG for that step (guidance_trunc)
- * S = 2B when any guidance[i] > 1 (cond rows then uncond rows), else S = B.
+ *   sched [steps]    host array of nova_sampler_step
+ *   noise [steps, B, n, P] f32 or NULL: the per-step gaussian rows of an ancestral sampler (used where sigma != 0)
+ *   renorm           guidance_renorm (>= 1: off). When < 1 (flow-matching Euler only): guidance_scaler.py:67-72 with
+ *                    echo_energy [B] f32 in/out = squared norm of each sample's rows that are NOT predicted in this AR
+ *                    step (they echo x_t in the reference and enter both norms), ws_v [2*B*n*P] f32 scratch.
+ * S = 2B when any sched[i].guidance > 1 (cond rows then uncond rows), else S = B.
  * Workspaces in `dtype`: ws_a, ws_u, ws_h, ws_f, ws_g [S*n, D]; ws_mod [S*n, (3*depth+2)*D]. */
-int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const float* dt,
-                         const float* guidance, int steps, int S, int B, int n, int P, int D, void* ws_a, void* ws_u,
-                         void* ws_h, void* ws_f, void* ws_g, void* ws_mod, int dtype, void* stream);
+int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
+                         const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
+                         void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int dtype,
+                         void* stream);
 
 #ifdef __cplusplus
 }

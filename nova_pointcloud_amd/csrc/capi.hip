@@ -203,7 +203,10 @@ int nova_head_cfg_euler(const void* h, const void* w, const float* bias, float* 
                         float guidance, int cfg, float dt, int dtype, void* stream) {
   NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "head_cfg_euler: bad dtype %d", dtype);
   NOVA_REQUIRE(h && w && bias && x, NOVA_ERR_ARG, "head_cfg_euler: null pointer");
-  return head_cfg_euler(h, w, bias, x, B, n, P, D, guidance, cfg, dt, dtype, (hipStream_t)stream);
+  // the kernel takes "guidance > 1" as the CFG switch; cfg != 0 with g <= 1 still combines (u + g (c - u))
+  NOVA_REQUIRE(!cfg || guidance > 1.0f, NOVA_ERR_ARG, "head_cfg_euler: cfg needs guidance > 1");
+  SamplerStep sp{cfg ? guidance : 1.0f, 0.f, 1.f, 0.f, dt, 1.f, 0.f};
+  return head_cfg_step(h, w, bias, x, nullptr, nullptr, nullptr, B, n, P, D, sp, 0, dtype, (hipStream_t)stream);
 }
 
 int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
@@ -237,21 +240,27 @@ int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, 
   return 0;
 }
 
-int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const float* dt,
-                         const float* guidance, int steps, int S, int B, int n, int P, int D, void* ws_a, void* ws_u,
-                         void* ws_h, void* ws_f, void* ws_g, void* ws_mod, int dtype, void* stream) {
+int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
+                         const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
+                         void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int dtype,
+                         void* stream) {
   NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "decoder_denoise: bad dtype %d", dtype);
-  NOVA_REQUIRE(dec && zc && temb && x && dt && guidance && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
+  NOVA_REQUIRE(dec && zc && temb && x && sched && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
                "decoder_denoise: null pointer");
   NOVA_REQUIRE(S == B || S == 2 * B, NOVA_ERR_SHAPE, "decoder_denoise: S must be B or 2B");
+  const bool do_renorm = renorm < 1.0f;
+  NOVA_REQUIRE(!do_renorm || (echo_energy && ws_v), NOVA_ERR_ARG, "decoder_denoise: renorm needs echo_energy and ws_v");
   if (n == 0 || B == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   const size_t es = esize(dtype);
   const int depth = dec->depth;
   const long mod_ld = (long)(3 * depth + 2) * D;
   for (int i = 0; i < steps; ++i) {
-    const int cfg = guidance[i] > 1.0f ? 1 : 0;
+    const SamplerStep sp{sched[i].guidance, sched[i].kx, sched[i].kv, sched[i].clip, sched[i].c0, sched[i].cx, sched[i].sigma};
+    const int cfg = sp.guidance > 1.0f ? 1 : 0;
     NOVA_REQUIRE(!cfg || S == 2 * B, NOVA_ERR_SHAPE, "decoder_denoise: guidance > 1 needs S = 2B");
+    NOVA_REQUIRE(!(do_renorm && cfg) || (sp.kx == 0.f && sp.kv == 1.f && sp.cx == 1.f && sp.sigma == 0.f && sp.clip <= 0.f),
+                 NOVA_ERR_ARG, "decoder_denoise: guidance renorm is built for the flow-matching Euler step only");
     const int Se = cfg ? 2 * B : B;
     const long rows = (long)Se * n;
     NOVA_TRY(silu_add_rows(zc, static_cast<const char*>(temb) + (size_t)i * D * es, ws_a, rows, D, dtype, st));
@@ -268,7 +277,15 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
     }
     RowNormArgs mf{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, depth * 3 * D, depth * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
     NOVA_TRY(row_norm(mf, dtype, st));
-    NOVA_TRY(head_cfg_euler(ws_h, dec->head_w, dec->head_b, x, B, n, P, D, guidance[i], cfg, dt[i], dtype, st));
+    const float* nz = (noise && sp.sigma != 0.f) ? noise + (size_t)i * B * n * P : nullptr;
+    if (do_renorm && cfg) {  // guidance_scaler.py:67-72: two small launches, norms over the whole sample
+      NOVA_TRY(head_cfg_step(ws_h, dec->head_w, dec->head_b, x, nullptr, ws_v, ws_v + (size_t)B * n * P, B, n, P, D, sp, 1, dtype, st));
+      NOVA_TRY(renorm_euler(x, ws_v, ws_v + (size_t)B * n * P, echo_energy, B, n, P, sp.c0, renorm, st));
+    } else {
+      NOVA_TRY(head_cfg_step(ws_h, dec->head_w, dec->head_b, x, nz, nullptr, nullptr, B, n, P, D, sp, 0, dtype, st));
+      // guidance switched off for this step (guidance_trunc): no renorm, but the echo rows still take the Euler step
+      if (do_renorm && echo_energy) NOVA_TRY(scale_vector(echo_energy, B, (1.0f + sp.c0) * (1.0f + sp.c0), st));
+    }
   }
   return 0;
 }

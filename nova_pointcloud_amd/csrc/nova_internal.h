@@ -64,7 +64,13 @@ int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D
 int timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, hipStream_t st);
 int patch_embed_rows(const float* x, const void* w, const float* bias, void* out, int S, int B, int n, int P, int D,
                      int dtype, hipStream_t st);
-int head_cfg_euler(const void* h, const void* w, const float* bias, float* x, int B, int n, int P, int D,
-                   float guidance, int cfg, float dt, int dtype, hipStream_t st);
+struct SamplerStep {  // == nova_sampler_step (include/nova_hip.h)
+  float guidance, kx, kv, clip, c0, cx, sigma;
+};
+int head_cfg_step(const void* h, const void* w, const float* bias, float* x, const float* noise, float* vhat, float* cond,
+                  int B, int n, int P, int D, const SamplerStep& sp, int defer, int dtype, hipStream_t st);
+int scale_vector(float* v, int n, float f, hipStream_t st);
+int renorm_euler(float* x, const float* vhat, const float* cond, float* echo, int B, int n, int P, float dt, float renorm,
+                 hipStream_t st);
 
 }  // namespace nova

@@ -12,7 +12,7 @@
 //                    (embeddings.py:160-166, 272-274, 90-91)
 //   build_sequence   cat([c ; gather(x, prev_ids)]) (vision_transformer.py:133-136)
 //   scatter_tokens   x_masked.scatter(1, prev_ids, x) (vision_transformer.py:141-143)
-//   silu_add_rows, timestep_freq, patch_embed_rows, head_cfg_euler: diffusion-MLP glue
+//   silu_add_rows, timestep_freq, patch_embed_rows, head_cfg_step, renorm_euler: diffusion-MLP glue and samplers
 //                    (diffusion_mlp.py:65-75,89-99; guidance_scaler.py:86-87; scheduling_cfm.py:134-136)
 #include "common.h"
 #include "nova_internal.h"
@@ -389,16 +389,23 @@ int patch_embed_rows(const float* x, const void* w, const float* bias, void* out
   return check_launch("patch_embed_rows");
 }
 
-// Head projection + classifier-free guidance + Euler step for the n tokens of this AR step:
-//   pc = Wh h[b][j] + bh, pu = Wh h[B + b][j] + bh, v = cfg ? pu + g (pc - pu) : pc,  x[b][j] += dt v
+// Head projection + classifier-free guidance + one sampler step for the n tokens of this AR step:
+//   pc = Wh h[b][j] + bh, pu = Wh h[B + b][j] + bh, v = cfg ? pu + g (pc - pu) : pc
+//   x0 = clamp(kx x + kv v, +-clip);  x <- c0 x0 + cx x + sigma noise
+// Flow-matching Euler (scheduling_cfm.py:134-136): kx = 0, kv = 1, no clip, c0 = dt, cx = 1, sigma = 0.
+// DDPM ancestral step (scheduling_ddpm.py:236-316): kx, kv from the prediction type, c0 / cx the posterior-mean
+// coefficients, sigma the posterior std, noise the fresh gaussian of that step.
+// defer != 0 (guidance renorm): do not touch x; write v to vhat[b][j][:] and pc to cond[b][j][:] instead.
 template <typename T>
-__global__ __launch_bounds__(256) void head_cfg_euler_kernel(const T* __restrict__ h, const T* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ x,
-                                                             long rows, int B, int n, int P, int D, float g, int cfg,
-                                                             float dt) {
+__global__ __launch_bounds__(256) void head_cfg_step_kernel(const T* __restrict__ h, const T* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ x,
+                                                            const float* __restrict__ noise, float* __restrict__ vhat,
+                                                            float* __restrict__ cond, long rows, int B, int n, int P, int D,
+                                                            SamplerStep sp, int defer) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // b * n + j
   if (row >= rows) return;
+  const int cfg = sp.guidance > 1.0f;
   const T* hc = h + row * D;
   const T* hu = h + ((long)B * n + row) * D;
   for (int p = 0; p < P; ++p) {
@@ -416,23 +423,88 @@ __global__ __launch_bounds__(256) void head_cfg_euler_kernel(const T* __restrict
     float vv = ac;
     if (cfg) {
       au = wave_sum(au) + bias[p];
-      vv = au + (ac - au) * g;
+      vv = au + (ac - au) * sp.guidance;
     }
-    if (lane == 0) x[row * P + p] += dt * vv;
+    if (lane == 0) {
+      const long e = row * P + p;
+      if (defer) {
+        vhat[e] = vv;
+        cond[e] = ac;
+      } else {
+        const float xo = x[e];
+        float x0 = sp.kx * xo + sp.kv * vv;
+        if (sp.clip > 0.f) x0 = fminf(fmaxf(x0, -sp.clip), sp.clip);
+        float xn = sp.c0 * x0 + sp.cx * xo;
+        if (noise) xn += sp.sigma * noise[e];
+        x[e] = xn;
+      }
+    }
   }
 }
 
-int head_cfg_euler(const void* h, const void* w, const float* bias, float* x, int B, int n, int P, int D,
-                   float guidance, int cfg, float dt, int dtype, hipStream_t st) {
+int head_cfg_step(const void* h, const void* w, const float* bias, float* x, const float* noise, float* vhat, float* cond,
+                  int B, int n, int P, int D, const SamplerStep& sp, int defer, int dtype, hipStream_t st) {
   const long rows = (long)B * n;
   if (rows <= 0) return 0;
-  if (D % 4) return set_error(NOVA_ERR_SHAPE, "head_cfg_euler: D %% 4 != 0");
+  if (D % 4) return set_error(NOVA_ERR_SHAPE, "head_cfg_step: D %% 4 != 0");
+  if (defer && (!vhat || !cond)) return set_error(NOVA_ERR_ARG, "head_cfg_step: deferred mode needs vhat and cond buffers");
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(head_cfg_euler_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)h, (const bf16_t*)w, bias, x, rows, B, n, P, D, guidance, cfg, dt);
+    hipLaunchKernelGGL(head_cfg_step_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)h, (const bf16_t*)w, bias, x, noise, vhat, cond, rows, B, n, P, D, sp, defer);
   else
-    hipLaunchKernelGGL(head_cfg_euler_kernel<float>, grid, block, 0, st, (const float*)h, (const float*)w, bias, x, rows, B, n, P, D, guidance, cfg, dt);
-  return check_launch("head_cfg_euler");
+    hipLaunchKernelGGL(head_cfg_step_kernel<float>, grid, block, 0, st, (const float*)h, (const float*)w, bias, x, noise, vhat, cond, rows, B, n, P, D, sp, defer);
+  return check_launch("head_cfg_step");
+}
+
+// Guidance renormalisation (guidance_scaler.py:67-72) for the flow-matching Euler step. The reference takes the
+// norms over ALL N rows of a sample: the n predicted rows plus the rows that merely echo the current x_t. The
+// echo rows never leave this kernel's view: their squared norm E_b is a scalar that evolves with the same step
+// (x_echo <- x_echo (1 + dt ratio)), so one block per sample reduces its n*P predicted values deterministically:
+//   ratio = clamp(sqrt((sum c^2 + E) / (sum v^2 + E)), renorm, 1);  x += dt ratio v;  E *= (1 + dt ratio)^2
+__global__ __launch_bounds__(256) void renorm_euler_kernel(float* __restrict__ x, const float* __restrict__ vhat,
+                                                          const float* __restrict__ cond, float* __restrict__ echo, int nP,
+                                                          float dt, float renorm) {
+  __shared__ float red[2][4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* vb = vhat + (long)b * nP;
+  const float* cb = cond + (long)b * nP;
+  float sv = 0.f, sc = 0.f;
+  for (int i = threadIdx.x; i < nP; i += 256) {
+    sv += vb[i] * vb[i];
+    sc += cb[i] * cb[i];
+  }
+  sv = wave_sum(sv);
+  sc = wave_sum(sc);
+  if (lane == 0) { red[0][wv] = sv; red[1][wv] = sc; }
+  __syncthreads();
+  const float E = echo[b];
+  const float nx = sqrtf((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) + E);
+  const float nc = sqrtf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + E);
+  const float ratio = fminf(fmaxf(nc / nx, renorm), 1.0f);
+  for (int i = threadIdx.x; i < nP; i += 256) x[(long)b * nP + i] += dt * (ratio * vb[i]);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float f = 1.0f + dt * ratio;
+    echo[b] = E * f * f;
+  }
+}
+
+__global__ void scale_vector_kernel(float* v, int n, float f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] *= f;
+}
+
+int scale_vector(float* v, int n, float f, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scale_vector_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v, n, f);
+  return check_launch("scale_vector");
+}
+
+int renorm_euler(float* x, const float* vhat, const float* cond, float* echo, int B, int n, int P, float dt, float renorm,
+                 hipStream_t st) {
+  if (B <= 0 || n <= 0) return 0;
+  hipLaunchKernelGGL(renorm_euler_kernel, dim3(B), dim3(256), 0, st, x, vhat, cond, echo, n * P, dt, renorm);
+  return check_launch("renorm_euler");
 }
 
 }  // namespace nova

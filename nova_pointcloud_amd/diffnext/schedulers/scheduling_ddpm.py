@@ -44,6 +44,12 @@ class DDPMScheduler(SchedulerMixin, ConfigMixin):
             betas = torch.sigmoid(torch.linspace(-6, 6, n)) * (beta_end - beta_start) + beta_start
         else:
             raise NotImplementedError(f"{beta_schedule} is not implemented for {self.__class__}")
+        if rescale_betas_zero_snr:  # zero terminal SNR (arXiv 2305.08891, algorithm 1)
+            abar_sqrt = torch.cumprod(1.0 - betas, dim=0).sqrt()
+            first, last = abar_sqrt[0].clone(), abar_sqrt[-1].clone()
+            abar_sqrt = (abar_sqrt - last) * first / (first - last)
+            abar = abar_sqrt**2
+            betas = 1 - torch.cat([abar[0:1], abar[1:] / abar[:-1]])
         self.betas, self.alphas = betas, 1.0 - betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
         self.one, self.init_noise_sigma = torch.tensor(1.0), 1.0
@@ -53,6 +59,14 @@ class DDPMScheduler(SchedulerMixin, ConfigMixin):
 
     def scale_model_input(self, sample, timestep=None):
         return sample
+
+    def sample_timesteps(self, size, device=None):
+        return torch.randint(0, self.config.num_train_timesteps, size, device=device)
+
+    def get_velocity(self, sample, noise, timesteps):
+        acp = self.alphas_cumprod.to(device=sample.device, dtype=sample.dtype)
+        shape = timesteps.shape + (1,) * (noise.dim() - timesteps.dim())
+        return acp[timesteps].sqrt().view(shape) * noise - (1 - acp[timesteps]).sqrt().view(shape) * sample
 
     def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None):
         n = self.config.num_train_timesteps
@@ -123,8 +137,8 @@ class DDPMScheduler(SchedulerMixin, ConfigMixin):
             x0 = a_t**0.5 * sample - b_t**0.5 * model_output
         else:
             raise ValueError(f"unknown prediction_type {kind}")
-        if self.config.clip_sample:
-            x0 = x0.clamp(-self.config.clip_sample_range, self.config.clip_sample_range)
+        # NB: like the reference's step (:268-300) there is no clip / dynamic-threshold stage; `clip_sample`,
+        # `thresholding` & co. are accepted config keys only.
         mean = (a_prev**0.5 * cur_beta / b_t) * x0 + (cur_alpha**0.5 * b_prev / b_t) * sample
         if t > 0:
             noise = torch.randn(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
@@ -138,7 +152,7 @@ class DDPMScheduler(SchedulerMixin, ConfigMixin):
 
     def add_noise(self, original_samples, noise, timesteps):
         acp = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
-        shape = (-1,) + (1,) * (original_samples.dim() - 1)
+        shape = timesteps.shape + (1,) * (noise.dim() - timesteps.dim())
         return acp[timesteps].sqrt().view(shape) * original_samples + (1 - acp[timesteps]).sqrt().view(shape) * noise
 
     def __len__(self):

@@ -105,6 +105,42 @@ class _Guidance(object):
         self.guidance_scale = self.inc_guidance_scale * decay + self.min_guidance_scale
 
 
+def sampler_plan(sched, steps):
+    """(timesteps f32[steps], per-step (kx, kv, clip, c0, cx, sigma), ancestral?) for `nova_sampler_step`:
+    x0 = clamp(kx x + kv v); x <- c0 x0 + cx x + sigma noise."""
+    kind = type(sched).__name__
+    sched.set_timesteps(steps)
+    if kind == "FlowMatchEulerDiscreteScheduler":  # scheduling_cfm.py:92-104,134-136
+        sig = sched.sigmas
+        return np.asarray(sched.timesteps, dtype="float32"), [(0.0, 1.0, 0.0, sig[j + 1] - sig[j], 1.0, 0.0) for j in range(steps)], False
+    if kind == "DDPMScheduler":  # scheduling_ddpm.py:236-316 (no clipping / thresholding stage in the reference's step)
+        if sched.variance_type not in ("fixed_small", "fixed_small_log", "fixed_large"):
+            raise NotImplementedError(f"DDPM variance_type {sched.variance_type} is not built on the HIP path")
+        ts = [int(t) for t in sched.timesteps]
+        coefs = []
+        for t in ts:
+            prev_t = int(sched.previous_timestep(t))
+            a_t = float(sched.alphas_cumprod[t])
+            a_prev = float(sched.alphas_cumprod[prev_t]) if prev_t >= 0 else 1.0
+            b_t, b_prev = 1 - a_t, 1 - a_prev
+            cur_alpha = a_t / a_prev
+            cur_beta = 1 - cur_alpha
+            kind_p = sched.config.prediction_type
+            if kind_p == "epsilon":
+                kx, kv = a_t ** -0.5, -(b_t ** 0.5) / a_t ** 0.5
+            elif kind_p == "sample":
+                kx, kv = 0.0, 1.0
+            elif kind_p == "v_prediction":
+                kx, kv = a_t ** 0.5, -(b_t ** 0.5)
+            else:
+                raise ValueError(f"Unsupported prediction type given as {kind_p}.")
+            var = max(b_prev / b_t * cur_beta, 1e-20)
+            sigma = 0.0 if t <= 0 else (cur_beta ** 0.5 if sched.variance_type == "fixed_large" else var ** 0.5)
+            coefs.append((kx, kv, 0.0, a_prev ** 0.5 * cur_beta / b_t, cur_alpha ** 0.5 * b_prev / b_t, sigma))
+        return np.asarray(ts, dtype="float32"), coefs, True
+    raise NotImplementedError(f"sampler {kind} is not built on the HIP path (flow-matching Euler and DDPM are)")
+
+
 def _params_signature(module):
     return tuple((p.data_ptr(), p._version, p.dtype) for p in module.parameters())
 
@@ -257,13 +293,9 @@ class NovaEngine(object):
         scaler = _Guidance(inputs)
         if scaler.extra_pass:
             raise NotImplementedError("3-pass (image / spatiotemporal) guidance is a video feature: not built on the HIP path")
-        if scaler.guidance_renorm < 1:
-            raise NotImplementedError("guidance_renorm < 1 is not built on the HIP path yet")
         if inputs.get("max_latent_length", 1) != 1:
             raise NotImplementedError("max_latent_length > 1 (video, KV-cached frames) is not built on the HIP path")
         sched = m.sample_scheduler
-        if not hasattr(sched, "sigmas") or type(sched).__name__ != "FlowMatchEulerDiscreteScheduler":
-            raise NotImplementedError(f"sampler {type(sched).__name__} is not built on the HIP path (flow-matching Euler is)")
 
         ie, ve = m.image_encoder, m.video_encoder
         C, (H, W), p = ie.image_dim, ie.image_size, ie.patch_embed.patch_size
@@ -282,10 +314,10 @@ class NovaEngine(object):
         rng_dev = "cpu" if host_rng else dev
 
         steps = inputs.get("num_diffusion_steps", 25)
-        sched.set_timesteps(steps)
-        timesteps = np.asarray(sched.timesteps, dtype="float32")
-        sig = sched.sigmas
-        dts = (ctypes.c_float * steps)(*[sig[j + 1] - sig[j] for j in range(steps)])
+        timesteps, coefs, ancestral = sampler_plan(sched, steps)
+        renorm = float(scaler.guidance_renorm)
+        if renorm < 1 and ancestral:
+            raise NotImplementedError("guidance_renorm < 1 with an ancestral sampler is not built on the HIP path")
         num_preds = [int(v) for v in inputs["num_preds"] if v > 0]
         nmax = max(num_preds) if num_preds else 1
         L2 = Nv + N
@@ -344,9 +376,10 @@ class NovaEngine(object):
             scaler.decay_guidance_scale((i + 1) / len(num_preds))
             if cfg_on and scaler.guidance_scale <= 1:
                 raise NotImplementedError("guidance decaying to <= 1 inside a CFG run is undefined in the reference")
-            g_step = (ctypes.c_float * steps)(*[
-                1.0 if (cfg_on and scaler.guidance_trunc and float(t) < scaler.guidance_trunc) else float(scaler.guidance_scale)
-                for t in timesteps])
+            plan = (hip.SamplerStep * steps)()
+            for j, t in enumerate(timesteps):
+                g = 1.0 if (cfg_on and scaler.guidance_trunc and float(t) < scaler.guidance_trunc) else float(scaler.guidance_scale)
+                plan[j] = hip.SamplerStep(g if cfg_on else 1.0, *coefs[j])
             z0 = ws["z0"]
             hip.call("nova_embed_canvas", canvas.data_ptr(), mask.data_ptr(), self.patch[0], self.patch[1], self.mask_token,
                      hip.ptr(img_pe), z0.data_ptr(), B, N, P, D, code, st())
@@ -379,9 +412,24 @@ class NovaEngine(object):
                 noise.normal_(generator=generator)
             nz = noise.to(dev).reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P)
             x_n = nz.gather(1, pred_ids[..., None].expand(-1, -1, P)).contiguous()
-            hip.call("nova_decoder_denoise", ctypes.byref(self.dec.struct), zc.data_ptr(), temb.data_ptr(), x_n.data_ptr(), dts,
-                     g_step, steps, S, B, n, P, D, ws["da"].data_ptr(), ws["du"].data_ptr(), ws["dh"].data_ptr(),
-                     ws["df"].data_ptr(), ws["dg"].data_ptr(), ws["dmod"].data_ptr(), code, st())
+            step_noise = echo = ws_v = None
+            if ancestral:  # RNG contract (scheduling_ddpm.py:303-305): one fresh gaussian [B,C,H,W] per step with t > 0
+                rows = []
+                for j in range(steps):
+                    if coefs[j][5] != 0.0:
+                        e = torch.randn(B, C, H, W, generator=generator, device=rng_dev, dtype=_F32).to(dev)
+                        e = e.reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P)
+                        rows.append(e.gather(1, pred_ids[..., None].expand(-1, -1, P)))
+                    else:
+                        rows.append(torch.zeros(B, n, P, dtype=_F32, device=dev))
+                step_noise = torch.stack(rows).contiguous()
+            if renorm < 1 and cfg_on:  # squared norm of the rows that only echo x_t in the reference (guidance_scaler.py:67-72)
+                echo = (nz.pow(2).sum((1, 2)) - x_n.pow(2).sum((1, 2))).clamp_min(0).contiguous()
+                ws_v = torch.empty(2 * B * n * P, dtype=_F32, device=dev)
+            hip.call("nova_decoder_denoise", ctypes.byref(self.dec.struct), zc.data_ptr(), temb.data_ptr(), x_n.data_ptr(), plan,
+                     hip.ptr(step_noise), renorm if cfg_on else 1.0, hip.ptr(echo), steps, S, B, n, P, D, ws["da"].data_ptr(),
+                     ws["du"].data_ptr(), ws["dh"].data_ptr(), ws["df"].data_ptr(), ws["dg"].data_ptr(), ws["dmod"].data_ptr(),
+                     hip.ptr(ws_v), code, st())
             canvas.scatter_(1, pred_ids[..., None].expand(-1, -1, P), x_n)
             done += n
         m.mask_embed.mask, m.mask_embed.pred_pos = mask.unsqueeze(-1).to(dtype), done

@@ -47,6 +47,12 @@ class Decoder(ctypes.Structure):
         "adaln_w", "adaln_b", "patch_w", "patch_b", "head_w", "head_b")]
 
 
+class SamplerStep(ctypes.Structure):
+    """``nova_sampler_step`` (include/nova_hip.h)."""
+
+    _fields_ = [(k, c_float) for k in ("guidance", "kx", "kv", "clip", "c0", "cx", "sigma")]
+
+
 # name -> argtypes; every function returns int status. Must list EVERY symbol of nova_hip.h
 # (tests/test_abi.py checks the header against this table and against the built library).
 SIGNATURES = {
@@ -65,8 +71,8 @@ SIGNATURES = {
     "nova_head_cfg_euler": [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_float, c_int, c_void_p],
     "nova_vit_blocks_forward": [ctypes.POINTER(VitBlock), c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_int]
     + [c_void_p] * 4 + [c_int, c_void_p],
-    "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_float),
-                             ctypes.POINTER(c_float)] + [c_int] * 6 + [c_void_p] * 6 + [c_int, c_void_p],
+    "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]
+    + [c_int] * 6 + [c_void_p] * 7 + [c_int, c_void_p],
 }
 SIGNATURES["nova_prof_enable"] = [c_int]
 SIGNATURES["nova_debug_force_gemm_tile"] = [c_int]

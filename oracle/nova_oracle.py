@@ -49,6 +49,46 @@ def cfm_sigmas(num_steps, shift=1.0, num_train_timesteps=1000):
     return sigmas * num_train_timesteps, sigmas.tolist() + [0]
 
 
+def ddpm_plan(num_steps, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+              prediction_type="epsilon", variance_type="fixed_small", timestep_spacing="leading", steps_offset=0):
+    """diffnext/schedulers/scheduling_ddpm.py:134-157 (betas), :182-209 (set_timesteps), :211-234 (_get_variance),
+    :236-316 (step). Returns per step (t, kx, kv, c0, cx, sigma) with x0 = kx x + kv v, x <- c0 x0 + cx x + sigma eps.
+    The reference's step has no clipping / thresholding stage. PARITY UNPINNED BY EXECUTION (class imports diffusers)."""
+    n = num_train_timesteps
+    if beta_schedule == "linear":
+        betas = torch.linspace(beta_start, beta_end, n, dtype=torch.float32)
+    elif beta_schedule == "scaled_linear":
+        betas = torch.linspace(beta_start**0.5, beta_end**0.5, n, dtype=torch.float32) ** 2
+    else:
+        raise NotImplementedError(beta_schedule)
+    acp = torch.cumprod(1.0 - betas, dim=0)
+    if timestep_spacing == "leading":
+        ts = (np.arange(0, num_steps) * (n // num_steps)).round()[::-1].copy().astype(np.int64) + steps_offset
+    elif timestep_spacing == "linspace":
+        ts = np.linspace(0, n - 1, num_steps).round()[::-1].copy().astype(np.int64)
+    elif timestep_spacing == "trailing":
+        ts = np.arange(n, 0, -n / num_steps).round().astype(np.int64) - 1
+    else:
+        raise ValueError(timestep_spacing)
+    plan = []
+    for t in [int(v) for v in ts]:
+        prev_t = t - n // num_steps
+        a_t, a_prev = acp[t], (acp[prev_t] if prev_t >= 0 else torch.tensor(1.0))
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        cur_alpha = a_t / a_prev
+        cur_beta = 1 - cur_alpha
+        if prediction_type == "epsilon":
+            kx, kv = 1 / a_t**0.5, -(b_t**0.5) / a_t**0.5
+        elif prediction_type == "sample":
+            kx, kv = torch.tensor(0.0), torch.tensor(1.0)
+        else:  # v_prediction
+            kx, kv = a_t**0.5, -(b_t**0.5)
+        var = torch.clamp(b_prev / b_t * cur_beta, min=1e-20)
+        sigma = (cur_beta if variance_type == "fixed_large" else var) ** 0.5 if t > 0 else torch.tensor(0.0)
+        plan.append((t, float(kx), float(kv), float(a_prev**0.5 * cur_beta / b_t), float(cur_alpha**0.5 * b_prev / b_t), float(sigma)))
+    return plan
+
+
 def encode_prompt_embeds(text_weight, prompt_embeds, num_tokens):
     """pipeline_nova.py:204-215 + embeddings.py:179-188 for the `prompt_embeds`, guidance > 1 path.
 
@@ -248,7 +288,8 @@ def make_config(image_dim, latent_hw, patch, embed_dim, heads, video_depth, imag
 
 
 def generate(p, cfg, prompt, num_preds, num_diffusion_steps=25, guidance_scale=5.0, generator=None,
-             shift=1.0, dtype=torch.float32, u_dist=None, noises=None, trace=None):
+             shift=1.0, dtype=torch.float32, u_dist=None, noises=None, trace=None, guidance_trunc=0, guidance_renorm=1,
+             ddpm=None):
     """Transformer3DModel.forward in eval mode for T = 1 (transformer_3d.py:63-77,102-164,192-200).
 
     prompt: [2B, Lt, token_dim] from encode_prompt_embeds. Returns x [B, C, 1, H, W].
@@ -270,6 +311,9 @@ def generate(p, cfg, prompt, num_preds, num_diffusion_steps=25, guidance_scale=5
     c_txt = layer_norm(F.linear(prompt.to(dtype), p["text_embed.proj.weight"], p["text_embed.proj.bias"]),
                        p["text_embed.norm.weight"], p["text_embed.norm.bias"])
     timesteps, sigmas = cfm_sigmas(num_diffusion_steps, shift)
+    ddpm_steps = ddpm_plan(num_diffusion_steps, **ddpm) if ddpm is not None else None
+    if ddpm_steps is not None:
+        timesteps = [np.int64(st[0]) for st in ddpm_steps]
 
     # generate_video :135-164, t = 0 only
     bos, mask_token = p["mask_embed.bos_token"], p["mask_embed.mask_token"]
@@ -315,17 +359,32 @@ def generate(p, cfg, prompt, num_preds, num_diffusion_steps=25, guidance_scale=5
             noise.normal_(generator=generator)
         else:
             noise = noises[i].to(dtype)
-        # denoise :102-113 (2-pass CFG, no truncation, no renorm)
+        # denoise :102-113 (2-pass CFG; guidance_trunc / guidance_renorm per guidance_scaler.py:59-72)
         xt = noise
+        zz, ids, cfg_live = z, pred_ids, cfg_on
         for j, t in enumerate(timesteps):
-            timestep = torch.as_tensor(t).expand(z.shape[0])
-            pred = diffusion_mlp(p, "image_decoder.", cfg.decoder_depth, expand(xt), timestep, z, pred_ids, patch)
-            if cfg_on:  # guidance_scaler.py:86-87
+            if cfg_live and guidance_trunc and float(t) < guidance_trunc:  # maybe_disable :59-65: stays off afterwards
+                cfg_live, zz, ids = False, zz.chunk(2)[0], ids.chunk(2)[0]
+            timestep = torch.as_tensor(t).expand(zz.shape[0])
+            x_in = expand(xt) if cfg_live else xt
+            pred = diffusion_mlp(p, "image_decoder.", cfg.decoder_depth, x_in, timestep, zz, ids, patch)
+            if cfg_live:  # scale :67-87
                 cond, uncond = pred.chunk(2)
                 pred = uncond + (cond - uncond) * guidance_scale
+                if guidance_renorm < 1:  # renorm :67-72, norms over every row of the sample (echo rows included)
+                    dims = tuple(range(1, pred.dim()))
+                    ratio = cond.norm(dim=dims, keepdim=True) / pred.norm(dim=dims, keepdim=True)
+                    pred = pred * ratio.clamp(guidance_renorm, 1)
             pred = unpatchify(pred, patch, C, h, w)
-            dt = sigmas[j + 1] - sigmas[j]  # scheduling_cfm.py:134-135
-            xt = pred * dt + xt
+            if ddpm_steps is None:
+                dt = sigmas[j + 1] - sigmas[j]  # scheduling_cfm.py:134-135
+                xt = pred * dt + xt
+            else:  # scheduling_ddpm.py:268-312
+                _, kx, kv, c0, cx, sigma = ddpm_steps[j]
+                x0 = kx * xt + kv * pred
+                xt = c0 * x0 + cx * xt
+                if int(t) > 0:
+                    xt = xt + sigma * torch.randn(xt.shape, generator=generator, dtype=dtype)
         sample = patchify(xt, patch)
         x = x + unpatchify(sample * pred_mask, patch, C, h, w)  # :133
     return x.unsqueeze(2)

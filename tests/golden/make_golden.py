@@ -150,6 +150,13 @@ def make_case(name, seed, D, heads, depths, latent_hw, token_dim, token_len, rot
     noises = [torch.empty(B, image_dim, *latent_hw).normal_(generator=gen2) for _ in steps]
     assert torch.equal(u_dist.argsort(dim=1), order), "generator replay does not match the reference's draw order"
 
+    # second run of the SAME model and seed with guidance truncation + renormalisation (guidance_scaler.py:59-72)
+    gen3 = torch.Generator().manual_seed(sample_seed)
+    inputs2 = dict(inputs, prompt=prompt.clone(), generator=gen3, guidance_trunc=450.0, guidance_renorm=0.3)
+    inputs2.pop("c", None), inputs2.pop("x", None), inputs2.pop("latents", None)
+    with torch.no_grad():
+        out2 = m(inputs2)["x"]
+
     (dx, dt, dz, dids), dout = dec_calls[0]
     sd = {k: v for k, v in m.state_dict().items()}
     arrays = {"w/" + k: bf16_bits(v) for k, v in sd.items()}
@@ -165,6 +172,7 @@ def make_case(name, seed, D, heads, depths, latent_hw, token_dim, token_len, rot
     arrays["in/u_dist"] = u_dist.numpy()
     arrays["in/noises"] = torch.stack(noises).numpy()
     arrays["out/x"] = out.numpy()
+    arrays["out/x_trunc450_renorm03"] = out2.numpy()
     arrays["out/order"] = order.numpy()
     arrays["out/c"] = trace["c"].numpy()
     arrays["out/z_first"] = trace["z"][0].numpy()

@@ -217,3 +217,26 @@ def test_head_dim_96_model_matches_oracle(hip):
         prompt_embeds=[p.cuda() for p in prompts], num_inference_steps=4, num_diffusion_steps=3, guidance_scale=4.0,
         generator=torch.Generator().manual_seed(5), output_type="latent", disable_progress_bar=True).frames
     assert torch.isfinite(x16.float()).all()
+
+
+def test_f32_pipeline_trunc_and_renorm_match_reference(gold, hip):
+    """guidance_trunc + guidance_renorm on the HIP path (per-step CFG switch; renorm with the echo-row energy scalar)."""
+    _, x = run_pipe(gold, torch.float32, guidance_trunc=450.0, guidance_renorm=0.3,
+                    generator=torch.Generator().manual_seed(gold.meta["sample_seed"]))
+    err = rel(x, gold.t["out/x_trunc450_renorm03"])
+    assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("pred_type", ["epsilon", "v_prediction"])
+def test_f32_pipeline_ddpm_matches_oracle(gold, hip, pred_type):
+    from diffnext.schedulers import DDPMScheduler
+
+    m = gold.meta
+    kw = dict(num_train_timesteps=1000, beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012, prediction_type=pred_type)
+    pipe = NOVAPipeline(transformer=build_from_golden(gold, torch.float32, "cuda"), scheduler=DDPMScheduler(**kw))
+    x = pipe(prompt_embeds=gold.prompt_embeds, num_inference_steps=m["K"], num_diffusion_steps=5, guidance_scale=m["guidance"],
+             generator=torch.Generator().manual_seed(33), output_type="latent", disable_progress_bar=True).frames
+    ref = O.generate(gold.weights, gold.oracle_config(), gold.t["in/prompt"], gold.t["in/num_preds"].numpy(), num_diffusion_steps=5,
+                     guidance_scale=m["guidance"], generator=torch.Generator().manual_seed(33), ddpm=kw)
+    err = rel(x, ref)
+    assert err < 1e-4, err

@@ -131,3 +131,27 @@ def test_guidance_le_one_runs_single_pass(gold):
     out = pipe(prompt_embeds=gold.prompt_embeds, num_inference_steps=2, num_diffusion_steps=2, guidance_scale=1,
                generator=torch.Generator().manual_seed(0), output_type="latent", disable_progress_bar=True)
     assert out.frames.shape[0] == m["B"] and torch.isfinite(out.frames).all()
+
+
+def test_pipeline_cpu_trunc_and_renorm_match_reference(gold):
+    m = gold.meta
+    pipe = NOVAPipeline(transformer=build_from_golden(gold), scheduler=FlowMatchEulerDiscreteScheduler())
+    out = pipe(prompt_embeds=gold.prompt_embeds, num_inference_steps=m["K"], num_diffusion_steps=m["S"],
+               guidance_scale=m["guidance"], guidance_trunc=450.0, guidance_renorm=0.3,
+               generator=torch.Generator().manual_seed(m["sample_seed"]), output_type="latent", disable_progress_bar=True)
+    ref = gold.t["out/x_trunc450_renorm03"]
+    assert (out.frames - ref).abs().max() <= 1e-5 * ref.abs().max()
+
+
+def test_pipeline_cpu_ddpm_matches_oracle(gold):
+    """Two independent restatements of scheduling_ddpm.py (the scheduler class here, oracle.ddpm_plan) agree."""
+    from oracle import nova_oracle as O
+
+    m = gold.meta
+    kw = dict(num_train_timesteps=1000, beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012, prediction_type="epsilon")
+    pipe = NOVAPipeline(transformer=build_from_golden(gold), scheduler=DDPMScheduler(**kw))
+    out = pipe(prompt_embeds=gold.prompt_embeds, num_inference_steps=m["K"], num_diffusion_steps=4, guidance_scale=m["guidance"],
+               generator=torch.Generator().manual_seed(21), output_type="latent", disable_progress_bar=True).frames
+    ref = O.generate(gold.weights, gold.oracle_config(), gold.t["in/prompt"], gold.t["in/num_preds"].numpy(), num_diffusion_steps=4,
+                     guidance_scale=m["guidance"], generator=torch.Generator().manual_seed(21), ddpm=kw)
+    assert (out - ref).abs().max() <= 2e-5 * ref.abs().max()

@@ -78,3 +78,22 @@ def test_generate_f64_replay_close_to_reference(gold):
     x, _ = _run(gold, torch.float64, replay=True)
     ref = gold.t["out/x"].double()
     assert (x - ref).abs().max() <= 5e-5 * ref.abs().max()
+
+
+def test_guidance_trunc_and_renorm_match_reference(gold):
+    """guidance_trunc=450 (timestep units) + guidance_renorm=0.3, run by the reference's own GuidanceScaler / denoise loop."""
+    m = gold.meta
+    x = O.generate(gold.weights, gold.oracle_config(), gold.t["in/prompt"], gold.t["in/num_preds"].numpy(),
+                   num_diffusion_steps=m["S"], guidance_scale=m["guidance"], guidance_trunc=450.0, guidance_renorm=0.3,
+                   generator=torch.Generator().manual_seed(m["sample_seed"]))
+    ref = gold.t["out/x_trunc450_renorm03"]
+    assert (x - ref).abs().max() <= 1e-5 * ref.abs().max()
+    assert (ref - gold.t["out/x"]).abs().max() > 1e-3 * ref.abs().max()  # the options really change the result
+
+
+def test_ddpm_plan_basics():
+    plan = O.ddpm_plan(10, num_train_timesteps=100)
+    assert [p[0] for p in plan] == list(range(90, -1, -10))
+    assert plan[-1][5] == 0.0 and all(p[5] > 0 for p in plan[:-1])  # no noise at t = 0
+    t, kx, kv, c0, cx, sigma = plan[-1]
+    assert abs(cx) < 1e-6 and abs(c0 - 1.0) < 1e-6  # last step returns the predicted x0
