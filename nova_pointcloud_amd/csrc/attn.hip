@@ -43,7 +43,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
   constexpr int NKS = HD / 16, NDV = HD / 32;
   constexpr int BUF = 2 * A_T64 + (HD == 96 ? 2 * A_T32 : 0);  // [K64 | V64 | K32 | V32]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases stay scalar
   const int r = lane & 31, hh = lane >> 5;
   // XCD-aware order: all query tiles of one (sequence, head) are consecutive in the remapped list, so they
   // run on one XCD and its K/V is served from that XCD's L2 after the first tile.
@@ -72,25 +73,43 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
   }
 
   // staging: wave w moves LDS-DMA pieces 2w, 2w+1 (8 rows x 128 B) of the 64-wide K and V images and, for
-  // HD = 96, piece w (16 rows x 64 B) of the 32-wide images
+  // HD = 96, piece w (16 rows x 64 B) of the 32-wide images. Per-lane byte offsets inside a tile are loop
+  // invariant (32-bit); the tile base advances as a wave-uniform scalar, so a full tile costs no vector address
+  // arithmetic. Only the ragged last tile recomputes clamped rows.
+  const uint32_t rowB = (uint32_t)kv_rs * 2u;
+  const int srow0 = (wid * 2) * 8 + (lane >> 3), srow1 = srow0 + 8, scp = lane & 7;
+  const int srow32 = wid * 16 + (lane >> 2), scp32 = lane & 3;
+  const uint32_t ck0 = (uint32_t)((scp ^ ((srow0 >> 1) & 7)) << 4), ck1 = (uint32_t)((scp ^ ((srow1 >> 1) & 7)) << 4);
+  const uint32_t cv0 = (uint32_t)((scp ^ (((srow0 >> 1) & 1) << 2)) << 4), cv1 = (uint32_t)((scp ^ (((srow1 >> 1) & 1) << 2)) << 4);
+  const uint32_t ck32 = 128u + (uint32_t)((scp32 ^ ((srow32 >> 2) & 3)) << 4), cv32 = 128u + (uint32_t)(scp32 << 4);
+  const uint32_t ko0 = srow0 * rowB + ck0, ko1 = srow1 * rowB + ck1, vo0 = srow0 * rowB + cv0, vo1 = srow1 * rowB + cv1;
+  const uint32_t ko32 = srow32 * rowB + ck32, vo32 = srow32 * rowB + cv32;
   auto stage = [&](int buf, int kt) {
     char* lk = smem + buf * BUF;
     char* lv = lk + A_T64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int piece = wid * 2 + i, row = piece * 8 + (lane >> 3), cp = lane & 7;
-      const int key = min(kt * A_KV + row, Lk - 1);
-      const int ck = cp ^ ((row >> 1) & 7);           // K image: conflict-free ds_read_b128 by row
-      const int cv = cp ^ (((row >> 1) & 1) << 2);    // V image: conflict-free ds_read_b64_tr_b16
-      __builtin_amdgcn_global_load_lds(kb_ + (size_t)key * kv_rs + ck * 8, NOVA_LDS_PTR(lk + piece * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(vb_ + (size_t)key * kv_rs + cv * 8, NOVA_LDS_PTR(lv + piece * 1024), 16, 0, 0);
-    }
-    if constexpr (HD == 96) {
-      const int row = wid * 16 + (lane >> 2), cp = lane & 3;
-      const int key = min(kt * A_KV + row, Lk - 1);
-      const int ck = cp ^ ((row >> 2) & 3);           // 64-byte rows: 4 rows per bank row
-      __builtin_amdgcn_global_load_lds(kb_ + (size_t)key * kv_rs + 64 + ck * 8, NOVA_LDS_PTR(lk + 2 * A_T64 + wid * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(vb_ + (size_t)key * kv_rs + 64 + cp * 8, NOVA_LDS_PTR(lk + 2 * A_T64 + A_T32 + wid * 1024), 16, 0, 0);
+    const char* kbase = reinterpret_cast<const char*>(kb_) + (size_t)kt * A_KV * rowB;  // wave-uniform
+    const char* vbase = reinterpret_cast<const char*>(vb_) + (size_t)kt * A_KV * rowB;
+    const int lim = Lk - 1 - kt * A_KV;  // last valid row of this tile
+    if (lim >= A_KV - 1) {
+      __builtin_amdgcn_global_load_lds(kbase + ko0, NOVA_LDS_PTR(lk + wid * 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vbase + vo0, NOVA_LDS_PTR(lv + wid * 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(kbase + ko1, NOVA_LDS_PTR(lk + wid * 2048 + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vbase + vo1, NOVA_LDS_PTR(lv + wid * 2048 + 1024), 16, 0, 0);
+      if constexpr (HD == 96) {
+        __builtin_amdgcn_global_load_lds(kbase + ko32, NOVA_LDS_PTR(lk + 2 * A_T64 + wid * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(vbase + vo32, NOVA_LDS_PTR(lk + 2 * A_T64 + A_T32 + wid * 1024), 16, 0, 0);
+      }
+    } else {  // ragged tile: rows past Lk re-read the last valid row (their scores are masked to -inf)
+      const uint32_t r0 = (uint32_t)min(srow0, lim) * rowB, r1 = (uint32_t)min(srow1, lim) * rowB;
+      __builtin_amdgcn_global_load_lds(kbase + (r0 + ck0), NOVA_LDS_PTR(lk + wid * 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vbase + (r0 + cv0), NOVA_LDS_PTR(lv + wid * 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(kbase + (r1 + ck1), NOVA_LDS_PTR(lk + wid * 2048 + 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(vbase + (r1 + cv1), NOVA_LDS_PTR(lv + wid * 2048 + 1024), 16, 0, 0);
+      if constexpr (HD == 96) {
+        const uint32_t r32 = (uint32_t)min(srow32, lim) * rowB;
+        __builtin_amdgcn_global_load_lds(kbase + (r32 + ck32), NOVA_LDS_PTR(lk + 2 * A_T64 + wid * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(vbase + (r32 + cv32), NOVA_LDS_PTR(lk + 2 * A_T64 + A_T32 + wid * 1024), 16, 0, 0);
+      }
     }
   };
 
