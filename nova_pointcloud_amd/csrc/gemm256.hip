@@ -65,6 +65,7 @@ __device__ __forceinline__ PFrag<T> punit_frag(const char* unit, int row, int ch
 }
 
 #define NOVA_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define NOVA_LOOP_BARRIER() do { if (VAR < 12) NOVA_BARRIER(); } while (0)
 
 // VAR selects where the two LDS-DMA instructions of a phase are issued (A/B-tested on the GPU, tools/microbench.py):
 //   0: both between the two k-halves of the MFMA segment   1: one in the load segment, one in the MFMA segment
@@ -92,17 +93,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   // unit order u: 0 = A(0), 1 = W(1), 2 = A(1), 3 = W(0)   (the staging order)
   const int cp = lane & 7;
   const size_t rowbytes = (size_t)K * sizeof(T);
-  const char* src[4][2];
+  // wave-uniform tile bases + per-lane 32-bit byte offsets: the LDS-DMA instructions then take an SGPR base and a
+  // 32-bit VGPR offset, and advancing along K is scalar arithmetic (no 64-bit vector add per issue)
+  const char* a_base = reinterpret_cast<const char*>(A) + (size_t)m0 * rowbytes;
+  const char* w_base = reinterpret_cast<const char*>(W) + (size_t)n0 * rowbytes;
+  uint32_t soff[4][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (wid * 2 + i) * 8 + (lane >> 3);          // row inside the unit, 0..127
-    const int c = (cp ^ ((r >> 1) & 7)) << 4;               // source chunk (swizzle on the source side)
+    const uint32_t c = (uint32_t)((cp ^ ((r >> 1) & 7)) << 4);  // source chunk (swizzle on the source side)
     const int a_lo = (r >> 6) * 128 + (r & 63);             // + mi*64
     const int w_lo = (r >> 5) * 64 + (r & 31);              // + ni*32
-    src[0][i] = reinterpret_cast<const char*>(A) + (size_t)min(m0 + a_lo, M - 1) * rowbytes + c;
-    src[2][i] = reinterpret_cast<const char*>(A) + (size_t)min(m0 + a_lo + 64, M - 1) * rowbytes + c;
-    src[3][i] = reinterpret_cast<const char*>(W) + (size_t)(n0 + w_lo) * rowbytes + c;
-    src[1][i] = reinterpret_cast<const char*>(W) + (size_t)(n0 + w_lo + 32) * rowbytes + c;
+    const int rmax = M - 1 - m0;                            // rows past M re-read row M-1 (never stored)
+    soff[0][i] = (uint32_t)min(a_lo, rmax) * (uint32_t)rowbytes + c;
+    soff[2][i] = (uint32_t)min(a_lo + 64, rmax) * (uint32_t)rowbytes + c;
+    soff[3][i] = (uint32_t)w_lo * (uint32_t)rowbytes + c;
+    soff[1][i] = (uint32_t)(w_lo + 32) * (uint32_t)rowbytes + c;
   }
   const int nkt = K / (128 / (int)sizeof(T));
   // LDS offset of unit u inside a buffer: A(0) A(1) W(0) W(1)
@@ -110,10 +116,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   auto stage_piece = [&](int u, int kt, int i) {
     if (kt < nkt) {
       char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048 + i * 1024;
-      __builtin_amdgcn_global_load_lds(src[u][i] + (size_t)kt * 128, NOVA_LDS_PTR(dst), 16, 0, 0);
+      const char* base = ((u == 0 || u == 2) ? a_base : w_base) + (size_t)kt * 128;
+      __builtin_amdgcn_global_load_lds(base + soff[u][i], NOVA_LDS_PTR(dst), 16, 0, 0);
     }
   };
   auto stage = [&](int u, int kt) {  // all 8 waves: 2 LDS-DMA instructions each (wave-uniform condition)
+    if (VAR >= 10 && kt >= 2) return;  // ablation builds (timing only, wrong results): no prefetch inside the loop
     stage_piece(u, kt, 0);
     stage_piece(u, kt, 1);
   };
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 
   PFrag<T> af[4][2], wf0[2][2], wf1[2][2];
   auto read_a = [&](const char* buf, int mi) {
+    if (VAR >= 11 && buf != smem) return;
     const char* u = buf + mi * P_UNIT;
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
       for (int kk = 0; kk < 2; ++kk) af[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
   };
   auto read_w = [&](const char* buf, int ni, PFrag<T> (&wf)[2][2]) {
+    if (VAR >= 11 && buf != smem) return;
     const char* u = buf + (2 + ni) * P_UNIT;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 
   auto lstage_pre = [&](int u, int kt) { if (VAR == 3) stage(u, kt); };
   auto lstage_post = [&](int u, int kt) {
-    if (VAR == 2) stage(u, kt);
+    if (VAR == 2 || VAR >= 10) stage(u, kt);
     if (VAR == 1) stage_piece(u, kt, 0);
   };
   for (int kt = 0; kt < nkt; ++kt) {
@@ -179,23 +189,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
     read_a(buf, 0);
     read_w(buf, 0, wf0);
     lstage_post(2, kt + 1);
-    NOVA_BARRIER();
+    NOVA_LOOP_BARRIER();
     mma_quadrant(0, 0, wf0, 2, kt + 1);
-    NOVA_BARRIER();
+    NOVA_LOOP_BARRIER();
     // phase 1: quadrant (0,1); stages (kt+1, W0)
     lstage_pre(3, kt + 1);
     read_w(buf, 1, wf1);
     lstage_post(3, kt + 1);
-    NOVA_BARRIER();
+    NOVA_LOOP_BARRIER();
     mma_quadrant(0, 1, wf1, 3, kt + 1);
-    NOVA_BARRIER();
+    NOVA_LOOP_BARRIER();
     // phase 2: quadrant (1,1); stages (kt+2, A0)
     lstage_pre(0, kt + 2);
     read_a(buf, 1);
     lstage_post(0, kt + 2);
-    NOVA_BARRIER();
+    NOVA_LOOP_BARRIER();
     mma_quadrant(1, 1, wf1, 0, kt + 2);
-    NOVA_BARRIER();
+    NOVA_LOOP_BARRIER();
     // phase 3: quadrant (1,0) on the W(0) fragments still held from phase 0 (no LDS reads); stages (kt+2, W1).
     // Before the first barrier: retire all of tile kt+1 = everything but the youngest unit issued so far
     // ((kt+2, A0) of phase 2; this phase's unit is issued after the barrier).
@@ -205,13 +215,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
     if (kt + 2 < nkt) {
       if (VAR == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       if (VAR == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      if (VAR >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (VAR >= 2 && VAR < 10) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (VAR >= 10) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    NOVA_BARRIER();
+    NOVA_LOOP_BARRIER();
     mma_quadrant(1, 0, wf0, 1, kt + 2);
-    NOVA_BARRIER();
+    NOVA_LOOP_BARRIER();
   }
   if (wr == 0) NOVA_BARRIER();  // re-align the groups
 
@@ -307,6 +318,9 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
     case 1: return launch256v<T, 1>(A, W, C, M, N, K, epi, e, st);
     case 3: return launch256v<T, 3>(A, W, C, M, N, K, epi, e, st);
     case 0: return launch256v<T, 0>(A, W, C, M, N, K, epi, e, st);
+    case 10: return launch256v<T, 10>(A, W, C, M, N, K, epi, e, st);
+    case 11: return launch256v<T, 11>(A, W, C, M, N, K, epi, e, st);
+    case 12: return launch256v<T, 12>(A, W, C, M, N, K, epi, e, st);
     default: return launch256v<T, 2>(A, W, C, M, N, K, epi, e, st);
   }
 }
