@@ -259,3 +259,62 @@ def test_two_lanes_equal_one_lane(hip, dtype):
     g = torch.Generator(device="cuda").manual_seed(3)
     c = run_pipe(gold, dtype, generator=g, lanes=2)[1]
     assert torch.isfinite(c.float()).all()
+
+
+def _tiny_model(D, heads, latent, image_dim, stride, rotary, seed, depths=(1, 2, 1)):
+    from diffnext.models.transformers import transformer_nova as TN
+
+    TN.VIDEO_ENCODERS.register(f"t_vit_d{depths[0]}w{D}", TN._vit, depth=depths[0], embed_dim=D, num_heads=heads)
+    TN.IMAGE_ENCODERS.register(f"t_vit_d{depths[1]}w{D}", TN._vit, depth=depths[1], embed_dim=D, num_heads=heads)
+    TN.IMAGE_DECODERS.register(f"t_mlp_d{depths[2]}w{D}", TN._mlp, depth=depths[2], embed_dim=D)
+    patch = 15 // stride + 1
+    base = [latent[0] // patch, latent[1] // patch]
+    torch.manual_seed(seed)
+    model = TN.NOVATransformer3DModel(
+        image_dim=image_dim, image_size=(latent[0] * stride, latent[1] * stride), image_stride=stride, text_token_dim=64,
+        text_token_len=8, image_base_size=base, video_base_size=[1, base[0] // 2, base[1] // 2], rotary_pos_embed=rotary,
+        arch=(f"t_vit_d{depths[0]}w{D}", f"t_vit_d{depths[1]}w{D}", f"t_mlp_d{depths[2]}w{D}")).eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("bias"):
+                p_.add_(torch.randn_like(p_) * 0.05)
+    cfg = O.make_config(image_dim, tuple(latent), patch, D, heads, depths[0], depths[1], depths[2], 8, rotary=rotary)
+    return model, {k: v.clone() for k, v in model.state_dict().items()}, cfg
+
+
+@pytest.mark.parametrize("rotary", [True, False])
+def test_image_like_geometry_patch2_matches_oracle(hip, rotary):
+    """The reference's image geometry: 4 latent channels, stride 8 -> patch 2 (P = 16 values per token), conditioning
+    encoder patch 4; exercises the conv-weight reordering and patchify order of the engine."""
+    model, sd, cfg = _tiny_model(128, 2, (16, 8), image_dim=4, stride=8, rotary=rotary, seed=5)
+    g = torch.Generator().manual_seed(9)
+    prompts = [torch.randn(4, 64, generator=g) * 0.5]
+    pipe = NOVAPipeline(transformer=model.cuda(), scheduler=FlowMatchEulerDiscreteScheduler())
+    out = pipe(prompt_embeds=[p.cuda() for p in prompts], num_inference_steps=3, num_diffusion_steps=3, guidance_scale=3.0,
+               generator=torch.Generator().manual_seed(2), output_type="latent", disable_progress_bar=True).frames
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 8)
+    ref = O.generate(sd, cfg, prompt, O.cosine_schedule(32, 3), num_diffusion_steps=3, guidance_scale=3.0,
+                     generator=torch.Generator().manual_seed(2))
+    assert out.shape == ref.shape == (1, 4, 1, 16, 8)
+    assert rel(out, ref) < 1e-4
+
+
+def test_pipeline_options_on_gpu_match_cpu_module_path(hip):
+    """num_images_per_prompt, negative_prompt_embeds, guidance <= 1 (single pass), more AR steps than tokens:
+    the HIP engine against this package's own PyTorch module path (itself pinned to the reference on the goldens)."""
+    gold = Golden("tiny_abspe")
+    m = gold.meta
+    g = torch.Generator().manual_seed(4)
+    neg = [torch.randn(3, m["token_dim"], generator=g) * 0.3]
+    cases = [dict(num_images_per_prompt=2, guidance_scale=4.0), dict(negative_prompt_embeds=neg, guidance_scale=2.5),
+             dict(guidance_scale=1.0), dict(num_inference_steps=100, guidance_scale=5.0, min_guidance_scale=2.0)]
+    for kw in cases:
+        outs = []
+        for dev in ("cpu", "cuda"):
+            pipe = NOVAPipeline(transformer=build_from_golden(gold, torch.float32, dev), scheduler=FlowMatchEulerDiscreteScheduler())
+            args = dict(prompt_embeds=[p.to(dev) for p in gold.prompt_embeds], num_inference_steps=m["K"], num_diffusion_steps=3,
+                        generator=torch.Generator().manual_seed(8), output_type="latent", disable_progress_bar=True)
+            args.update({k: ([t.to(dev) for t in v] if k == "negative_prompt_embeds" else v) for k, v in kw.items()})
+            outs.append(pipe(**args).frames)
+        assert outs[0].shape == outs[1].shape
+        assert rel(outs[1], outs[0]) < 1e-4, kw
