@@ -189,8 +189,13 @@ int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, i
                    hipStream_t st);
 
 void gemm256_set_variant(int v);
+void gemm256_set_gm(int g);
 static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
 void gemm_force_tile(int tile) {
+  if (tile >= 7000 && tile < 7100) {  // 7000 + g: row panels per tile group of the 256 kernel (A/B experiments)
+    gemm256_set_gm(tile - 7000);
+    return;
+  }
   if (tile >= 2560) {  // 2560 + v: force the 256 tile with schedule variant v (A/B experiments)
     gemm256_set_variant(tile - 2560);
     tile = 256;

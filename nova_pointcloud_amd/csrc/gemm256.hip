@@ -40,6 +40,7 @@ struct GemmEpi256 {
   int L, rope_batch, hd, rope_cols;
   float q_scale;
   int q_cols;
+  int gm;  // row panels per tile group (L2 reuse shape)
 };
 
 enum { E_NONE = 0, E_GELU = 1, E_SILU = 2, E_ROPE = 3 };
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 
   const int nwg = ntm * ntn;
   const int t = xcd_remap(blockIdx.x, nwg);
-  constexpr int GM = 8;
+  const int GM = e.gm;
   const int per_group = GM * ntn;
   const int group = t / per_group, first_m = group * GM;
   const int gsz = min(ntm - first_m, GM);
@@ -289,6 +290,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   }
 }
 
+static int g_gm256 = 8;
+void gemm256_set_gm(int g) { g_gm256 = g; }
 static int g_var256 = 2;  // measured best (tools/gemm_variants.py): LDS-DMA issued in the load segment, after the reads
 void gemm256_set_variant(int v) { g_var256 = v; }
 
@@ -330,7 +333,7 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
                    hipStream_t st) {
-  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols};
+  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256};
   return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st) : launch256<float>(A, W, C, M, N, K, epi, e, st);
 }
 
