@@ -190,8 +190,13 @@ int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, i
 
 void gemm256_set_variant(int v);
 void gemm256_set_gm(int g);
+void gemm256_set_stagger(int cycles);
 static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
 void gemm_force_tile(int tile) {
+  if (tile >= 30000 && tile < 31000) {  // 30000 + x: start stagger of the persistent 256 kernel, x * 256 cycles (experiments)
+    gemm256_set_stagger((tile - 30000) * 256);
+    return;
+  }
   if (tile >= 7000 && tile < 7100) {  // 7000 + g: row panels per tile group of the 256 kernel (A/B experiments)
     gemm256_set_gm(tile - 7000);
     return;

@@ -24,6 +24,7 @@
 // Epilogue: bias/GELU/SiLU/RoPE lane-local as in gemm.hip; bf16 results of two fragments are exchanged with
 // v_permlane16_swap so every lane stores 16 contiguous bytes (half the store instructions of the 8-byte form).
 // Results are bit-identical to gemm.hip (same MFMA, same k order): tests/test_gpu_kernels.py compares them.
+#include <type_traits>
 #include "common.h"
 #include "nova_internal.h"
 
@@ -41,6 +42,7 @@ struct GemmEpi256 {
   float q_scale;
   int q_cols;
   int gm;  // row panels per tile group (L2 reuse shape)
+  int stagger;  // persistent form: start delay of the last workgroup in cycles (0 = none), see gemm256p_kernel
 };
 
 enum { E_NONE = 0, E_GELU = 1, E_SILU = 2, E_ROPE = 3 };
@@ -290,9 +292,288 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Persistent form: one workgroup per CU walks its XCD's chunk of the tile list (same tile order as the
+// one-tile-per-workgroup launch above). What it buys on the K = 1024 shapes, where a tile's main loop is only
+// 16 K-tiles long: no workgroup dispatch between tiles, and the first six LDS-DMA units of the NEXT tile are
+// issued in the middle of the epilogue (after the re-align barrier every LDS slot is dead), so their HBM/L2
+// latency hides under the second half of the epilogue's VALU work and stores. vmcnt retires in issue order
+// and counts stores, so the wait at the top of the next tile is vmcnt(4 + stores of the second half).
+// Everything the second half needs from memory (RoPE table rows) is loaded BEFORE those DMAs are issued: a
+// load issued after them could only be consumed once they have all landed.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                          T* __restrict__ C, int M, int N, int K, int ntm, int ntn,
+                                                          GemmEpi256 e) {
+  constexpr int STORES_TILE = sizeof(T) == 2 ? 16 : 32;  // global stores a wave issues per tile epilogue
+  __shared__ __attribute__((aligned(16))) char smem[P_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+
+  // this workgroup's share of the tile list: XCD x = blockIdx % 8 owns one contiguous chunk (xcd_remap's
+  // split), its gridDim/8 workgroups take that chunk's tiles round-robin
+  const int nwg = ntm * ntn;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int cq = nwg >> 3, cr = nwg & 7;
+  const int cbase = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+  const int csize = cq + (xcd < cr ? 1 : 0);
+  if (slot >= csize) return;  // workgroup-uniform, before any barrier
+
+  const int GM = e.gm;
+  const int per_group = GM * ntn;
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int group = t / per_group, first_m = group * GM;
+    const int gsz = min(ntm - first_m, GM);
+    m0 = (first_m + (t % per_group) % gsz) * 256;
+    n0 = ((t % per_group) / gsz) * 256;
+  };
+
+  // Lane-derived values (fragment rows, DMA source offsets) are re-derived from an opaque copy of the lane id once
+  // per tile and once per epilogue: kept as kernel-lifetime invariants they occupy ~45 VGPRs across the epilogue,
+  // which then spills its RoPE table rows.
+  auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+  const size_t rowbytes = (size_t)K * sizeof(T);
+  const char *a_base, *w_base;
+  uint32_t soff[4][2];
+  auto set_tile = [&](int m0, int n0) {
+    const int lane = fresh_lane(), cp = lane & 7;
+    a_base = reinterpret_cast<const char*>(A) + (size_t)m0 * rowbytes;
+    w_base = reinterpret_cast<const char*>(W) + (size_t)n0 * rowbytes;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (wid * 2 + i) * 8 + (lane >> 3);
+      const uint32_t c = (uint32_t)((cp ^ ((r >> 1) & 7)) << 4);
+      const int a_lo = (r >> 6) * 128 + (r & 63);
+      const int w_lo = (r >> 5) * 64 + (r & 31);
+      const int rmax = M - 1 - m0;
+      soff[0][i] = (uint32_t)min(a_lo, rmax) * (uint32_t)rowbytes + c;
+      soff[2][i] = (uint32_t)min(a_lo + 64, rmax) * (uint32_t)rowbytes + c;
+      soff[3][i] = (uint32_t)w_lo * (uint32_t)rowbytes + c;
+      soff[1][i] = (uint32_t)(w_lo + 32) * (uint32_t)rowbytes + c;
+    }
+  };
+  const int nkt = K / (128 / (int)sizeof(T));
+  auto unit_off = [](int u) { return (u == 0 ? 0 : u == 2 ? 1 : u == 3 ? 2 : 3) * P_UNIT; };
+  auto stage = [&](int u, int kt) {
+    if (kt < nkt) {
+      char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048;
+      const char* base = ((u == 0 || u == 2) ? a_base : w_base) + (size_t)kt * 128;
+      __builtin_amdgcn_global_load_lds(base + soff[u][0], NOVA_LDS_PTR(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(base + soff[u][1], NOVA_LDS_PTR(dst + 1024), 16, 0, 0);
+    }
+  };
+  auto stage_prologue = [&]() {
+    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+    stage(0, 1); stage(1, 1);
+  };
+
+  int fr, fg;
+  f4v acc[4][8];  // [nf][mf]
+  PFrag<T> af[4][2], wf0[2][2], wf1[2][2];
+  auto read_a = [&](const char* buf, int mi) {
+    const char* u = buf + mi * P_UNIT;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) af[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
+  };
+  auto read_w = [&](const char* buf, int ni, PFrag<T> (&wf)[2][2]) {
+    const char* u = buf + (2 + ni) * P_UNIT;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) wf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
+  };
+  auto mma_quadrant = [&](int mi, int ni, PFrag<T> (&wf)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], acc[ni * 2 + nf][mi * 4 + mf]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  if (e.stagger > 0) {  // phase-shift the workgroups so that their epilogue store bursts do not coincide chip-wide
+    const long long until = clock64() + (long long)e.stagger * (int)blockIdx.x / (int)gridDim.x;
+    while (clock64() < until) __builtin_amdgcn_s_sleep(8);
+  }
+  int m0, n0;
+  int it = slot;
+  tile_origin(cbase + it, m0, n0);
+  set_tile(m0, n0);
+  stage_prologue();
+  bool first = true;
+  for (;;) {
+    { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
+    // K-tile 0 of this tile landed: all but (tile 1: A0, W1) and, after the first tile, everything the previous
+    // epilogue issued after the prologue DMAs (at least its STORES_TILE stores)
+    if (nkt == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (first) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + STORES_TILE) : "memory");
+    NOVA_BARRIER();
+    if (wr == 1) NOVA_BARRIER();  // group 1 runs one barrier behind group 0 inside the K loop
+    f4v bv[4];  // bias of this tile's columns: requested here, landed long before the epilogue
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
+    if (e.bias) {
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
+    }
+
+    for (int kt = 0; kt < nkt; ++kt) {
+      const char* buf = smem + (kt & 1) * P_BUF;
+      read_a(buf, 0);
+      read_w(buf, 0, wf0);
+      stage(2, kt + 1);
+      NOVA_BARRIER();
+      mma_quadrant(0, 0, wf0);
+      NOVA_BARRIER();
+      read_w(buf, 1, wf1);
+      stage(3, kt + 1);
+      NOVA_BARRIER();
+      mma_quadrant(0, 1, wf1);
+      NOVA_BARRIER();
+      read_a(buf, 1);
+      stage(0, kt + 2);
+      NOVA_BARRIER();
+      mma_quadrant(1, 1, wf1);
+      NOVA_BARRIER();
+      stage(1, kt + 2);
+      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      NOVA_BARRIER();
+      mma_quadrant(1, 0, wf0);
+      NOVA_BARRIER();
+    }
+    if (wr == 0) NOVA_BARRIER();  // re-align the groups: every LDS slot is dead from here on
+
+    // ---- epilogue
+    // (opaque copies: otherwise the row/table address arithmetic below is hoisted above the K loop and its
+    // results are spilled around it)
+    int cm0 = m0, cn0 = n0;
+    asm volatile("" : "+s"(cm0), "+s"(cn0));
+    { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
+    const bool rot = EPI == E_ROPE && cn0 < e.rope_cols;
+    const float qmul = (EPI == E_ROPE && cn0 < e.q_cols) ? e.q_scale : 1.0f;  // tile-uniform; x * 1.0f is exact
+    // four groups of 2 fragment row blocks. The next tile's prologue DMAs go out FIRST, ahead of this tile's stores in
+    // the memory pipeline (issued behind them they queue for ~7k cycles). What the epilogue needs from memory before
+    // it can start (bias, the RoPE rows of groups 0-1) is therefore consumed before the DMAs are issued; the RoPE rows
+    // of groups 2-3 are requested after them and arrive behind them (in-order retirement), by which time they are done.
+    f4v cs[4][2][4];  // [group][row block][nf]
+    int coff[4];      // column of this lane's 4 floats inside a table row (head-relative), per nf
+    if (rot) {
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) coff[nf] = (cn0 + wc * 64 + nf * 16 + fg * 4) % e.hd;
+    }
+    const int nxt = it + nslot;
+    const bool more = nxt < csize;
+    auto load_cs = [&](int g) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // (sequence, position) of the row block's first row on wave-uniform values, the lane's row by increment
+        const int mb = min(__builtin_amdgcn_readfirstlane(cm0 + wr * 128 + (2 * g + j) * 16), M - 1);
+        const int s0 = mb / e.L, l0 = mb - s0 * e.L;
+        const int b0 = s0 % e.rope_batch, b1 = b0 + 1 == e.rope_batch ? 0 : b0 + 1;
+        int l = l0 + min(fr, M - 1 - mb);  // rows past M reuse row M-1 (never stored differently)
+        int sb = b0;
+        if (l >= e.L) { l -= e.L; sb = b1; }  // a 16-row block crosses at most one sequence boundary (L >= 16)
+        const float* ropem = e.rope + ((size_t)sb * e.L + l) * e.hd;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) cs[g][j][nf] = *reinterpret_cast<const f4v*>(ropem + coff[nf]);
+      }
+    };
+    auto finish_group = [&](int g, auto rotated) {
+      constexpr bool ROT = decltype(rotated)::value;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int mf = 2 * g + j;
+        // rows past M were staged as copies of row M-1, so their lanes hold row M-1's results and store the identical
+        // bytes there again: no branch, and every tile issues the same number of stores (the vmcnt count above)
+        const int m = min(cm0 + wr * 128 + mf * 16 + fr, M - 1);
+        u2v pk[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          f4v v = acc[nf][mf] + bv[nf];
+          if (EPI == E_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = sizeof(T) == 2 ? gelu_erf_fast(v[q]) : gelu_erf(v[q]);
+          } else if (EPI == E_SILU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+          } else if (EPI == E_ROPE) {
+            if constexpr (ROT) {
+              const f4v t = cs[g][j][nf];
+              const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+              v[0] = t[0] * x0 - t[1] * x1;
+              v[1] = t[1] * x0 + t[0] * x1;
+              v[2] = t[2] * x2 - t[3] * x3;
+              v[3] = t[3] * x2 + t[2] * x3;
+            }
+            v = v * qmul;
+          }
+          if constexpr (sizeof(T) == 2) {
+            pk[nf] = u2v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+          } else {
+            *reinterpret_cast<f4v*>(C + (size_t)m * N + cn0 + wc * 64 + fg * 4 + nf * 16) = v;
+          }
+        }
+        if constexpr (sizeof(T) == 2) {  // 16-byte stores through v_permlane16_swap, as in the kernel above
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const auto lo = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+            const auto hi = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+            u4v o = {lo[0], hi[0], lo[1], hi[1]};
+            *reinterpret_cast<u4v*>(C + (size_t)m * N + cn0 + wc * 64 + (2 * pr + (fg & 1)) * 16 + (fg >> 1) * 8) = o;
+          }
+        }
+      }
+    };
+    auto next_prologue = [&]() {
+      if (more) {
+        tile_origin(cbase + nxt, m0, n0);
+        set_tile(m0, n0);
+        stage_prologue();
+      }
+    };
+    // the rotation is tile-uniform (decided per 256-column tile): two straight-line epilogues behind one scalar branch
+    asm volatile("" ::"v"(bv[3]));  // the compiler's wait for the bias sits here, before the DMAs
+    if (rot) {
+      load_cs(0);
+      load_cs(1);
+      asm volatile("" ::"v"(cs[1][1][3]));  // same for the table rows of groups 0-1 (loads retire in order)
+      next_prologue();
+      finish_group(0, std::true_type{});
+      finish_group(1, std::true_type{});
+      __builtin_amdgcn_sched_barrier(0);  // keep the later groups' table loads below groups 0-1 (register budget)
+      load_cs(2);
+      load_cs(3);
+      finish_group(2, std::true_type{});
+      finish_group(3, std::true_type{});
+    } else {
+      next_prologue();
+      finish_group(0, std::false_type{});
+      finish_group(1, std::false_type{});
+      finish_group(2, std::false_type{});
+      finish_group(3, std::false_type{});
+    }
+    if (!more) break;
+    first = false;
+    it = nxt;
+  }
+}
+
 static int g_gm256 = 8;
+static int g_stagger256 = 0;
+void gemm256_set_stagger(int cycles) { g_stagger256 = cycles; }
 void gemm256_set_gm(int g) { g_gm256 = g; }
-static int g_var256 = 2;  // measured best (tools/gemm_variants.py): LDS-DMA issued in the load segment, after the reads
+static int g_var256 = 20;  // measured best (tools/gemm_variants.py): the persistent form; 0-3 = one tile per workgroup, LDS-DMA placement variants
 void gemm256_set_variant(int v) { g_var256 = v; }
 
 template <typename T, int VAR>
@@ -314,9 +595,40 @@ static int launch256v(const void* A, const void* W, void* C, int M, int N, int K
   return check_launch("gemm256");
 }
 
+static int cu_slots() {  // persistent grid: one workgroup per CU, a multiple of the 8 XCDs
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    n = cus & ~7;
+  }
+  return n;
+}
+
+template <typename T>
+static int launch256p(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
+                      hipStream_t st) {
+  const int ntm = (M + 255) / 256, ntn = N / 256;
+  dim3 grid(cu_slots()), block(512);
+  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  const T* a = static_cast<const T*>(A);
+  const T* w = static_cast<const T*>(W);
+  T* c = static_cast<T*>(C);
+  switch (epi) {
+    case E_NONE: hipLaunchKernelGGL((gemm256p_kernel<T, E_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_GELU: hipLaunchKernelGGL((gemm256p_kernel<T, E_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_SILU: hipLaunchKernelGGL((gemm256p_kernel<T, E_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_ROPE: hipLaunchKernelGGL((gemm256p_kernel<T, E_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    default: return set_error(NOVA_ERR_ARG, "gemm256: unknown epilogue %d", epi);
+  }
+  return check_launch("gemm256p");
+}
+
 template <typename T>
 static int launch256(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
                      hipStream_t st) {
+  // (the persistent RoPE epilogue steps through a 16-row block assuming it crosses at most one sequence boundary)
+  if (g_var256 == 20 && !(epi == E_ROPE && e.rope && e.L < 16)) return launch256p<T>(A, W, C, M, N, K, epi, e, st);
   switch (g_var256) {
     case 1: return launch256v<T, 1>(A, W, C, M, N, K, epi, e, st);
     case 3: return launch256v<T, 3>(A, W, C, M, N, K, epi, e, st);
@@ -333,7 +645,7 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
                    hipStream_t st) {
-  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256};
+  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, g_stagger256};
   return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st) : launch256<float>(A, W, C, M, N, K, epi, e, st);
 }
 

@@ -245,6 +245,11 @@ def test_decoder_glue(hip, dtype):
 # the 256x256 ping-pong GEMM (large M) must be bit-identical to the 128x128 structure: same MFMA,
 # same k order per output element. Any LDS race (stale or half-landed tile) breaks equality.
 # ---------------------------------------------------------------------------------------------
+# the two 256x256 structures: one tile per workgroup (2560 + 2: its shipped schedule variant) and the persistent
+# one-workgroup-per-CU form (2560 + 20)
+TILE256_FORMS = [2562, 2580]
+
+
 @pytest.fixture()
 def force_tile(hip):
     def _force(tile):
@@ -256,12 +261,13 @@ def force_tile(hip):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,act", [(256, 256, 64, 0), (300, 256, 128, 2), (1000, 512, 192, 1), (4096, 256, 1024, 0),
                                         (8192 + 77, 1024, 1024, 1), (2560 * 3 + 1, 768, 3072, 0)])
-def test_gemm_256_tile_bitwise_equals_128_tile(hip, force_tile, dtype, M, N, K, act):
+@pytest.mark.parametrize("form", TILE256_FORMS)
+def test_gemm_256_tile_bitwise_equals_128_tile(hip, force_tile, form, dtype, M, N, K, act):
     a, w = rnd(M, K, dtype=dtype, seed=41), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=42)
     bias = rnd(N, seed=43)
     force_tile(128)
     ref = hip.gemm_bias_act(a, w, bias, act)
-    force_tile(256)
+    force_tile(form)
     out = hip.gemm_bias_act(a, w, bias, act)
     assert torch.equal(out, ref)
     full = a.float() @ w.float().T + bias
@@ -269,23 +275,27 @@ def test_gemm_256_tile_bitwise_equals_128_tile(hip, force_tile, dtype, M, N, K, 
     assert relerr(out, full) < tol(dtype)
 
 
-def test_gemm_256_tile_qkv_rope_bitwise(hip, force_tile):
-    S, L, D, heads, nb = 4, 301, 256, 4, 2
+@pytest.mark.parametrize("form", TILE256_FORMS)
+@pytest.mark.parametrize("S,L", [(4, 301), (16, 257), (3, 1400)])
+def test_gemm_256_tile_qkv_rope_bitwise(hip, force_tile, form, S, L):
+    D, heads, nb = 256, 4, 2
     hd = D // heads
     for dtype in DTYPES:
         x, w, b = rnd(S * L, D, dtype=dtype), rnd(3 * D, D, dtype=dtype, scale=D ** -0.5, seed=5), rnd(3 * D, seed=6)
-        pos = grid_pos(20, 20)
+        side = int((L - 11) ** 0.5) + 1
+        pos = grid_pos(side, side)
         g = torch.Generator().manual_seed(1)
-        ids = torch.stack([torch.randperm(400, generator=g)[: L - 11] for _ in range(nb)]).to(DEV)
+        ids = torch.stack([torch.randperm(side * side, generator=g)[: L - 11] for _ in range(nb)]).to(DEV)
         tab = hip.rope_table(pos, ids, 11, inv_freq(hd), nb, hd)
         force_tile(128)
         ref = hip.qkv_rope(x, w, b, tab, S, L, heads)
-        force_tile(256)
+        force_tile(form)
         out = hip.qkv_rope(x, w, b, tab, S, L, heads)
         assert torch.equal(out, ref)
 
 
-def test_gemm_256_tile_race_screen(hip, force_tile):
+@pytest.mark.parametrize("form", TILE256_FORMS)
+def test_gemm_256_tile_race_screen(hip, force_tile, form):
     """Full-size encoder GEMM shapes, repeated: every launch must reproduce the first bit for bit,
     and match the 128-tile structure (uneven M so that row clamping is exercised)."""
     dtype = torch.bfloat16
@@ -293,7 +303,7 @@ def test_gemm_256_tile_race_screen(hip, force_tile):
         a, w = rnd(M, K, dtype=dtype, seed=51), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=52)
         force_tile(128)
         ref = hip.gemm_bias_act(a, w, None, 0)
-        force_tile(256)
+        force_tile(form)
         for _ in range(6):
             out = hip.gemm_bias_act(a, w, None, 0)
             assert torch.equal(out, ref)
