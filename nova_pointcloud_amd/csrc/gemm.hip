@@ -191,8 +191,13 @@ int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, i
 void gemm256_set_variant(int v);
 void gemm256_set_gm(int g);
 void gemm256_set_stagger(int cycles);
+void gemm256_set_grid(int n);
 static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
 void gemm_force_tile(int tile) {
+  if (tile >= 40000 && tile <= 40512) {  // 40000 + n: persistent grid of n workgroups (0 = one per CU)
+    gemm256_set_grid(tile - 40000);
+    return;
+  }
   if (tile >= 30000 && tile < 31000) {  // 30000 + x: start stagger of the persistent 256 kernel, x * 256 cycles (experiments)
     gemm256_set_stagger((tile - 30000) * 256);
     return;

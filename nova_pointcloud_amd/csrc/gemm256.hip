@@ -595,7 +595,10 @@ static int launch256v(const void* A, const void* W, void* C, int M, int N, int K
   return check_launch("gemm256");
 }
 
+static int g_grid256 = 0;  // 0 = one workgroup per CU; otherwise the persistent grid size (a multiple of 8)
+void gemm256_set_grid(int n) { g_grid256 = n & ~7; }
 static int cu_slots() {  // persistent grid: one workgroup per CU, a multiple of the 8 XCDs
+  if (g_grid256 > 0) return g_grid256;
   static int n = 0;
   if (n == 0) {
     int dev = 0, cus = 0;

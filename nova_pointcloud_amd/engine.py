@@ -21,6 +21,8 @@ Data layout in HBM (all row-major, one token per row):
 import ctypes
 
 import numpy as np
+import os
+
 import torch
 
 from . import hip
@@ -296,7 +298,7 @@ class NovaEngine(object):
     def generate(self, inputs):
         """Eval-mode `Transformer3DModel.forward` body for max_latent_length == 1. Returns x [B,C,1,H,W].
 
-        The batch may be run as two half-batch LANES on two HIP streams (`inputs["lanes"]`, default 2 for 4 <= B <= 16):
+        The batch may be run as two half-batch LANES on two HIP streams (`inputs["lanes"]`, default 2 for B >= 4):
         samples are independent, so while one lane is in its latency-bound denoise loop (hundreds of small launches)
         the other lane's encoder GEMMs fill the idle CUs. All random draws stay here, for the whole batch and in the
         reference's order, and the lanes receive row slices - results do not depend on the number of lanes.
@@ -355,10 +357,13 @@ class NovaEngine(object):
                          for j in range(steps)]
             return nz, extra
 
-        # measured (MI355X): two lanes +6 % at batch 8 (d48w768 / 1024 points), -0.7 % at batch 32 (d48w1024 / 2048 points,
-        # where the denoise loop is only ~6 % of the step and half-size GEMMs cost more than the overlap returns)
-        lanes = int(inputs.get("lanes", 0)) or (2 if 4 <= B <= 16 else 1)
+        # measured (MI355X): two lanes +6 % at batch 8 (d48w768 / 1024 points) and +3 % at batch 32 (d48w1024 / 2048 points)
+        # once the encoder GEMMs are persistent (one lane's row kernels, decoder launches and epilogue store bursts fill
+        # the other's memory-idle K loops); four lanes lose 10 % (quarter-size GEMMs). NOVA_LANES overrides for experiments.
+        lanes = int(inputs.get("lanes", 0)) or int(os.environ.get("NOVA_LANES", 0)) or (2 if B >= 4 else 1)
         lanes = max(1, min(lanes, B))
+        if "NOVA_GEMM_GRID" in os.environ:  # experiments: persistent encoder-GEMM grid (workgroups), 0 = one per CU
+            hip.call("nova_debug_force_gemm_tile", 40000 + int(os.environ["NOVA_GEMM_GRID"]))
         main = torch.cuda.current_stream()
         bounds = [(B * k // lanes, B * (k + 1) // lanes) for k in range(lanes)]
         prompt = prompt.to(device=dev, dtype=dtype)
