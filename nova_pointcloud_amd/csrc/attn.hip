@@ -39,7 +39,7 @@ template <int HD>
 __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                     const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                                     int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
-                                                                    int heads, int nq) {
+                                                                    int heads, int nq, int rev) {
   constexpr int NKS = HD / 16, NDV = HD / 32;
   constexpr int BUF = 2 * A_T64 + (HD == 96 ? 2 * A_T32 : 0);  // [K64 | V64 | K32 | V32]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
   const int r = lane & 31, hh = lane >> 5;
   // XCD-aware order: all query tiles of one (sequence, head) are consecutive in the remapped list, so they
   // run on one XCD and its K/V is served from that XCD's L2 after the first tile.
-  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int t = xcd_remap_dir(blockIdx.x, gridDim.x, rev != 0);
   const int sh = t / nq, qt = t - sh * nq;
   const int head = sh % heads, s = sh / heads;
   const int q0 = qt * 128 + wid * 32;
@@ -390,8 +390,9 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (dtype == NOVA_BF16) {
     const float cl = q_prescaled ? 1.0f : c;
     const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v;
-    if (hd == 64) hipLaunchKernelGGL(attn_bf16<64>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq);
-    else hipLaunchKernelGGL(attn_bf16<96>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq);
+    const int rev = walk_is_reverse() ? 1 : 0;
+    if (hd == 64) hipLaunchKernelGGL(attn_bf16<64>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev);
+    else hipLaunchKernelGGL(attn_bf16<96>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev);
   } else {
     const float *qq = (const float*)q, *kk = (const float*)k, *vv = (const float*)v;
     if (hd == 64) hipLaunchKernelGGL(attn_f32<64>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);

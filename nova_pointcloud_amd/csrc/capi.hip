@@ -70,6 +70,14 @@ using namespace nova;
     if (rc_ != 0) return rc_; \
   } while (0)
 
+namespace nova {
+static bool g_walk_rev = false;
+void walk_reverse(bool on) { g_walk_rev = on; }
+bool walk_is_reverse() { return g_walk_rev; }
+static int g_walk_alternate = 1;  // experiments: nova_debug_force_gemm_tile(50000 / 50001) switches the alternation off / on
+void walk_set_alternate(int on) { g_walk_alternate = on; }
+}  // namespace nova
+
 extern "C" {
 
 int nova_version(void) { return NOVA_HIP_VERSION; }
@@ -86,7 +94,7 @@ int nova_check_device(void) {
 }
 
 int nova_debug_force_gemm_tile(int tile) {
-  NOVA_REQUIRE(tile == 0 || tile == 128 || tile == 256 || (tile >= 2560 && tile <= 2580) || (tile >= 7001 && tile <= 7064) || (tile >= 30000 && tile < 31000) || (tile >= 40000 && tile <= 40512), NOVA_ERR_ARG, "force_gemm_tile: 0, 128, 256 or 2560+variant");
+  NOVA_REQUIRE(tile == 0 || tile == 128 || tile == 256 || (tile >= 2560 && tile <= 2580) || (tile >= 7001 && tile <= 7064) || (tile >= 30000 && tile < 31000) || (tile >= 40000 && tile <= 40512) || tile == 50000 || tile == 50001, NOVA_ERR_ARG, "force_gemm_tile: 0, 128, 256 or 2560+variant");
   gemm_force_tile(tile);
   return 0;
 }
@@ -209,6 +217,7 @@ int nova_head_cfg_euler(const void* h, const void* w, const float* bias, float* 
   return head_cfg_step(h, w, bias, x, nullptr, nullptr, nullptr, B, n, P, D, sp, 0, dtype, (hipStream_t)stream);
 }
 
+
 int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
                             int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
                             void* ws_h, int dtype, void* stream) {
@@ -221,20 +230,33 @@ int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, 
   const size_t es = esize(dtype);
   const float scale = 1.0f / sqrtf((float)hd);
   const char* qkv = static_cast<const char*>(ws_qkv);
+  // every launch walks its row tiles in the opposite direction of the previous one (fresh-first reads, common.h)
+  struct Walk {
+    int k = 0;
+    void next() { walk_reverse(g_walk_alternate && (k++ & 1)); }
+    ~Walk() { walk_reverse(false); }
+  } walk;
   for (int i = 0; i < nblocks; ++i) {
     const nova_vit_block& b = blocks[i];
     // bf16: the softmax scale (in the exp2 domain) is folded into q by the QKV epilogue, before the bf16 rounding
     const bool pre = dtype == NOVA_BF16;
+    walk.next();
     NOVA_TRY(gemm_qkv_rope(x, b.qkv_w, b.qkv_b, rope, ws_qkv, S, L, D, heads, rope_batch, dtype, st,
                            pre ? scale * 1.4426950408889634f : 1.0f));
+    walk.next();
     NOVA_TRY(attn_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, ws_a, S, heads, L, L, hd, 3L * D, 3L * D, D,
                       scale, dtype, st, pre));
+    walk.next();
     NOVA_TRY(gemm_bias_act(ws_a, b.proj_w, b.proj_b, ws_b, M, D, D, NOVA_ACT_NONE, dtype, st));
     RowNormArgs n1{ws_b, x, b.norm1_w, b.norm1_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
+    walk.next();
     NOVA_TRY(row_norm(n1, dtype, st));
+    walk.next();
     NOVA_TRY(gemm_bias_act(x, b.fc1_w, b.fc1_b, ws_h, M, hidden, D, NOVA_ACT_GELU_ERF, dtype, st));
+    walk.next();
     NOVA_TRY(gemm_bias_act(ws_h, b.fc2_w, b.fc2_b, ws_b, M, D, hidden, NOVA_ACT_NONE, dtype, st));
     RowNormArgs n2{ws_b, x, b.norm2_w, b.norm2_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
+    walk.next();
     NOVA_TRY(row_norm(n2, dtype, st));
   }
   return 0;

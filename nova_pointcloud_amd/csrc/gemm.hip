@@ -192,8 +192,13 @@ void gemm256_set_variant(int v);
 void gemm256_set_gm(int g);
 void gemm256_set_stagger(int cycles);
 void gemm256_set_grid(int n);
+void walk_set_alternate(int on);
 static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
 void gemm_force_tile(int tile) {
+  if (tile == 50000 || tile == 50001) {  // alternate the walk direction between launches of a block (off / on)
+    walk_set_alternate(tile - 50000);
+    return;
+  }
   if (tile >= 40000 && tile <= 40512) {  // 40000 + n: persistent grid of n workgroups (0 = one per CU)
     gemm256_set_grid(tile - 40000);
     return;

@@ -42,6 +42,7 @@ struct GemmEpi256 {
   float q_scale;
   int q_cols;
   int gm;  // row panels per tile group (L2 reuse shape)
+  int rev;      // persistent form: walk each XCD's chunk of the tile list back to front (xcd_remap_dir, common.h)
   int stagger;  // persistent form: start delay of the last workgroup in cycles (0 = none), see gemm256p_kernel
 };
 
@@ -402,7 +403,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   }
   int m0, n0;
   int it = slot;
-  tile_origin(cbase + it, m0, n0);
+  auto tile_at = [&](int i) { return cbase + (e.rev ? csize - 1 - i : i); };
+  tile_origin(tile_at(it), m0, n0);
   set_tile(m0, n0);
   stage_prologue();
   bool first = true;
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
     };
     auto next_prologue = [&]() {
       if (more) {
-        tile_origin(cbase + nxt, m0, n0);
+        tile_origin(tile_at(nxt), m0, n0);
         set_tile(m0, n0);
         stage_prologue();
       }
@@ -648,7 +650,7 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
                    hipStream_t st) {
-  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, g_stagger256};
+  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, walk_is_reverse() ? 1 : 0, g_stagger256};
   return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st) : launch256<float>(A, W, C, M, N, K, epi, e, st);
 }
 

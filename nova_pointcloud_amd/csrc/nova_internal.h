@@ -29,6 +29,10 @@ int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const floa
 int gemm_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
                    int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st);
 void gemm_force_tile(int tile);
+// traversal direction of the NEXT launches of the row-tiled kernels (persistent GEMM, attention, row_norm); see
+// xcd_remap_dir in common.h. Set by the block composites, false for direct calls of the single-kernel entry points.
+void walk_reverse(bool on);
+bool walk_is_reverse();
 
 // ---- attn.hip
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
@@ -49,6 +53,7 @@ struct RowNormArgs {
   long rows;
   int D;
   float eps;
+  int rev = 0;           // set by row_norm() from walk_is_reverse(); callers leave it
 };
 int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
 

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
   using C = Chunk<T>;
   constexpr int NV = C::N / 4;
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // XCD x walks one contiguous eighth of the rows, front to back or back to front (xcd_remap_dir, common.h)
+  const long row = (long)xcd_remap_dir(blockIdx.x, gridDim.x, a.rev != 0) * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const long src = a.gather ? (long)a.gather[row] : row;
   const T* in = static_cast<const T*>(a.in) + src * a.D;
@@ -142,17 +143,19 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
     return set_error(NOVA_ERR_SHAPE, "row_norm: modulation offsets must be multiples of %d", vec);
   if ((a.gamma == nullptr) != (a.beta == nullptr)) return set_error(NOVA_ERR_ARG, "row_norm: gamma/beta must come together");
   dim3 grid((unsigned)((a.rows + 3) / 4));
+  RowNormArgs ar = a;
+  ar.rev = walk_is_reverse() ? 1 : 0;
   // algorithmic bytes: read in (+res, +mod terms) and write out once
   const double esz = dtype == NOVA_BF16 ? 2.0 : 4.0;
   const int nmod = a.mod ? ((a.scale_off >= 0 ? 2 : 0) + (a.gate_off >= 0 ? 1 : 0)) : 0;
   ProfScope prof(PROF_ROWNORM, esz * a.rows * a.D * (2.0 + (a.res ? 1 : 0) + nmod), st);
   const int chunks = (a.D / vec + 63) / 64;  // 16-byte chunks per lane
   if (dtype == NOVA_BF16) {
-    if (chunks <= 2) launch_row_norm<bf16_t, 2>(a, grid, st);
-    else launch_row_norm<bf16_t, 4>(a, grid, st);
+    if (chunks <= 2) launch_row_norm<bf16_t, 2>(ar, grid, st);
+    else launch_row_norm<bf16_t, 4>(ar, grid, st);
   } else {
-    if (chunks <= 4) launch_row_norm<float, 4>(a, grid, st);
-    else launch_row_norm<float, 8>(a, grid, st);
+    if (chunks <= 4) launch_row_norm<float, 4>(ar, grid, st);
+    else launch_row_norm<float, 8>(ar, grid, st);
   }
   return check_launch("row_norm");
 }

@@ -362,6 +362,8 @@ class NovaEngine(object):
         # the other's memory-idle K loops); four lanes lose 10 % (quarter-size GEMMs). NOVA_LANES overrides for experiments.
         lanes = int(inputs.get("lanes", 0)) or int(os.environ.get("NOVA_LANES", 0)) or (2 if B >= 4 else 1)
         lanes = max(1, min(lanes, B))
+        if "NOVA_WALK_ALT" in os.environ:  # experiments: alternate the tile-walk direction between launches (1) or not (0)
+            hip.call("nova_debug_force_gemm_tile", 50000 + int(os.environ["NOVA_WALK_ALT"]))
         if "NOVA_GEMM_GRID" in os.environ:  # experiments: persistent encoder-GEMM grid (workgroups), 0 = one per CU
             hip.call("nova_debug_force_gemm_tile", 40000 + int(os.environ["NOVA_GEMM_GRID"]))
         main = torch.cuda.current_stream()
