@@ -28,8 +28,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> one dword of two bf16 with ONE v_cvt_pk_bf16_f32 (the scalar-convert-shift-or form costs 3-4 VALU
+// issues per pair, which in the un-overlapped GEMM epilogues is paid 64 times per lane per tile)
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const bf2v h = __builtin_convertvector(f2v{lo, hi}, bf2v);
+  return __builtin_bit_cast(uint32_t, h);
 }
 
 template <typename T> __device__ __forceinline__ float to_f(T v);
@@ -49,18 +52,19 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
-// exact-erf GELU to ~1.5e-7 absolute (Abramowitz-Stegun 7.1.26): 1 rcp + 1 exp2 + 7 FMA-class ops instead
-// of libm erff's ~30; used where the result is rounded to bf16 anyway (bf16 eps = 3.9e-3).
+// erf-GELU for results that are rounded to bf16 anyway: x * sigmoid(x * q(x^2)), q an even quintic fitted (minimax,
+// tools/fit_gelu.py) to 0.5 x (1 + erf(x / sqrt 2)): max abs error 2.5e-5 over all x, i.e. <= 1.5 % of a bf16 ulp
+// wherever |gelu| >= 0.25 and far below the rounding of the bf16 value it is stored as. 9 VALU issues (2 of them the
+// 8-cycle exp2 / rcp) against ~25 for an erfc-polynomial form: in the fc1 epilogue this is 128 values per lane per
+// 256x256 tile with no matrix work to hide under (measured: the old form cost 37 % of the fc1 tile period).
+// Coefficients carry the -log2(e) of the exp2 domain. x^2 is clamped at 64: beyond |x| = 8 the sigmoid is 0 or 1 to
+// 1e-11 and the quintic would turn over at |x| ~ 10.7. The f32 parity path keeps libm's erff (gelu_erf).
 __device__ __forceinline__ float gelu_erf_fast(float x) {
-  const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);  // 1 - erf(z)
-  const float half_x = 0.5f * x;
-  return x >= 0.f ? fmaf(-half_x, e, x) : half_x * e;  // 0.5x(1 + erf) = x - 0.5x e ; 0.5x(1 - erf(|.|)) = 0.5x e
+  const float x2 = fminf(x * x, 64.0f);
+  float q = fmaf(1.0142630601e-3f, x2, -1.0677572399e-1f);
+  q = fmaf(q, x2, -2.3011213396e+0f);
+  const float e = __builtin_amdgcn_exp2f(q * x);  // exp(-x q(x^2))
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a

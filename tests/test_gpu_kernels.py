@@ -42,6 +42,26 @@ def test_gemm_bias_act(hip, dtype, M, N, K, act):
     assert relerr(out, ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("tile", [128, 2580])
+def test_gelu_epilogue_pointwise_accuracy(hip, force_tile, tile):
+    """W = I makes the accumulator equal the bf16 input exactly, so the epilogue's GELU is seen pointwise: every bf16
+    value in [-16, 16] must come out within 2.6e-5 (the fitted form's bound, csrc/common.h) plus the final bf16
+    rounding of the exact erf GELU (reference: nn.GELU() on the fc1 output, vision_transformer.py:36)."""
+    vals = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).view(torch.bfloat16)
+    vals = vals[torch.isfinite(vals.float()) & (vals.float().abs() <= 16)]
+    K = N = 256
+    M = (vals.numel() + K - 1) // K
+    a = torch.zeros(M * K, dtype=torch.bfloat16)
+    a[: vals.numel()] = vals
+    a = a.view(M, K).to(DEV)
+    force_tile(tile)
+    out = hip.gemm_bias_act(a, torch.eye(K, dtype=torch.bfloat16, device=DEV), None, 1).float().cpu().double()
+    x = a.float().cpu().double()
+    exact = 0.5 * x * (1 + torch.erf(x / 2 ** 0.5))
+    half_ulp = exact.abs().clamp_min(2.0 ** -126) * 2.0 ** -8  # generous half-ulp bound of a bf16 result
+    assert ((out - exact).abs() <= 2.6e-5 + half_ulp).all()
+
+
 def test_gemm_layout_asymmetric(hip):
     """A = I against an asymmetric W catches a transposed C write or a wrong fragment map."""
     K = N = 128
