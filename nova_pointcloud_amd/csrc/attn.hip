@@ -91,24 +91,24 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
     const char* vbase = reinterpret_cast<const char*>(vb_) + (size_t)kt * A_KV * rowB;
     const int lim = Lk - 1 - kt * A_KV;  // last valid row of this tile
     if (lim >= A_KV - 1) {
-      __builtin_amdgcn_global_load_lds(kbase + ko0, NOVA_LDS_PTR(lk + wid * 2048), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(vbase + vo0, NOVA_LDS_PTR(lv + wid * 2048), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(kbase + ko1, NOVA_LDS_PTR(lk + wid * 2048 + 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(vbase + vo1, NOVA_LDS_PTR(lv + wid * 2048 + 1024), 16, 0, 0);
+      glds16(kbase, ko0, lk + wid * 2048);
+      glds16(vbase, vo0, lv + wid * 2048);
+      glds16(kbase, ko1, lk + wid * 2048 + 1024);
+      glds16(vbase, vo1, lv + wid * 2048 + 1024);
       if constexpr (HD == 96) {
-        __builtin_amdgcn_global_load_lds(kbase + ko32, NOVA_LDS_PTR(lk + 2 * A_T64 + wid * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(vbase + vo32, NOVA_LDS_PTR(lk + 2 * A_T64 + A_T32 + wid * 1024), 16, 0, 0);
+        glds16(kbase, ko32, lk + 2 * A_T64 + wid * 1024);
+        glds16(vbase, vo32, lk + 2 * A_T64 + A_T32 + wid * 1024);
       }
     } else {  // ragged tile: rows past Lk re-read the last valid row (their scores are masked to -inf)
       const uint32_t r0 = (uint32_t)min(srow0, lim) * rowB, r1 = (uint32_t)min(srow1, lim) * rowB;
-      __builtin_amdgcn_global_load_lds(kbase + (r0 + ck0), NOVA_LDS_PTR(lk + wid * 2048), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(vbase + (r0 + cv0), NOVA_LDS_PTR(lv + wid * 2048), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(kbase + (r1 + ck1), NOVA_LDS_PTR(lk + wid * 2048 + 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(vbase + (r1 + cv1), NOVA_LDS_PTR(lv + wid * 2048 + 1024), 16, 0, 0);
+      glds16(kbase, r0 + ck0, lk + wid * 2048);
+      glds16(vbase, r0 + cv0, lv + wid * 2048);
+      glds16(kbase, r1 + ck1, lk + wid * 2048 + 1024);
+      glds16(vbase, r1 + cv1, lv + wid * 2048 + 1024);
       if constexpr (HD == 96) {
         const uint32_t r32 = (uint32_t)min(srow32, lim) * rowB;
-        __builtin_amdgcn_global_load_lds(kbase + (r32 + ck32), NOVA_LDS_PTR(lk + 2 * A_T64 + wid * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(vbase + (r32 + cv32), NOVA_LDS_PTR(lk + 2 * A_T64 + A_T32 + wid * 1024), 16, 0, 0);
+        glds16(kbase, r32 + ck32, lk + 2 * A_T64 + wid * 1024);
+        glds16(vbase, r32 + cv32, lk + 2 * A_T64 + A_T32 + wid * 1024);
       }
     }
   };
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
   const int nkt = (Lk + A_KV - 1) / A_KV;
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt (asm LDS-DMA: not counted by the compiler)
     __syncthreads();
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     const char* tk = smem + (kt & 1) * BUF;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
     for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[0][i]);
 #pragma unroll
     for (int i = 0; i < 16; ++i) mx = fmaxf(mx, st[1][i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor32(mx);
     // st already holds s*c - m_run (c folded into q, -m_run carried in by the first MFMA): mx is the growth of the
     // running max in the exp2 domain. Deferred rescale: O, l and the carried max only move when some query of the
     // wave grew by more than 2^8 (always on the first tile); until then p <= 2^8, exact in the f32 accumulators and
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void attn_f32(const float* __restrict__ q, con
     float mx = st[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(mx, st[i]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = max_xor32(mx);
     const float m_new = fmaxf(m_run, mx);
     const float alpha = exp2f((m_run - m_new) * c);
     const float mc = m_new * c;

@@ -20,6 +20,20 @@ typedef uint16_t bf16_t;  // storage type for bf16 tensors
 
 #define NOVA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// 16-byte LDS-DMA with a wave-uniform 64-bit base in SGPRs and a per-lane 32-bit byte offset (the instruction's saddr
+// form). Through the builtin the compiler materialises a 64-bit VGPR address per issue (v_lshl_add_u64, plus one more
+// per loop-carried pointer), which in the VALU-bound attention loop is ~8 two-pass instructions per tile.
+// M0 carries the LDS destination and is compiler-reserved: saved and restored inside the statement. The load is
+// invisible to the compiler's s_waitcnt bookkeeping: callers wait with an explicit s_waitcnt vmcnt.
+__device__ __forceinline__ void glds16(const void* base_uniform, uint32_t byte_off, const void* lds_dst_uniform) {
+  uint32_t keep;
+  const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)lds_dst_uniform;  // LDS byte offset
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(byte_off), "s"(base_uniform), "s"(dst)
+               : "memory");
+}
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even via the hardware cvt (keeps NaN a NaN, MI355X_MICROARCH correctness table)
@@ -47,6 +61,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+}
+
+// max over a lane and its partner lane ^ 32 without the LDS round trip of ds_bpermute: v_permlane32_swap of x with
+// itself leaves (x.lo, x.lo) and (x.hi, x.hi) in the two results
+__device__ __forceinline__ float max_xor32(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
