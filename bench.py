@@ -212,7 +212,7 @@ def main():
         value = world * B * N * args.steps / elapsed
         e2e_tflops = value / N * fl / 1e12 / world  # per GPU
         fams = {k: {"ms": round(ms, 2), "launches": n,
-                    "rate": round(wk / ms / (1e6 if k == "row_norm" else 1e9), 2) if ms > 0 else 0.0,
+                    "rate": round(wk / ms / (1e6 if k == "row_norm" else 1e9), 2) if ms > 0 else 0.0,  # GB/s | TFLOP/s
                     "unit": "GB/s" if k == "row_norm" else "TFLOP/s"} for k, (ms, wk, n) in prof.items() if n}
         mfma = {k: v for k, v in fams.items() if k != "row_norm"}
         if dry:
@@ -226,8 +226,8 @@ def main():
         # the process); the committed summary is for the largest launch of that kernel, so it is reported with its context.
         traffic, traffic_note = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if dom == "attention" and args.workload == "d48w1024_2048pts_b32":
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[dom]
+            if args.workload == "d48w1024_2048pts_b32":
                 traffic = pmc["hbm_bytes_per_launch"]
                 traffic_note = (f"PMC bytes of the {pmc['launch']} launch ({pmc['source']}); algorithmic bytes of that launch "
                                 f"{pmc['algorithmic_bytes_per_launch'] / 1e6:.1f} MB")

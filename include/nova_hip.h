@@ -48,9 +48,10 @@ int nova_check_device(void);
 /* ---- measurement hooks (bench.py): HIP-event timing of the GEMM / attention / row-norm launches on
  * the stream they are launched on. nova_prof_enable(1) starts recording; nova_prof_collect waits
  * for the recorded events and returns, per slot, summed milliseconds, summed algorithmic work
- * (FLOPs for slots 0-4, bytes for slot 5) and launch counts, then clears the record.
- * Slots: 0 gemm+bias, 1 gemm+bias+GELU, 2 gemm+bias+SiLU, 3 qkv gemm+RoPE, 4 attention, 5 row_norm. */
-#define NOVA_PROF_SLOTS 6
+ * (FLOPs for slots 0-4 and 6, bytes for slot 5) and launch counts, then clears the record.
+ * Slots 0-3: the large-M (256x256 tile) GEMM kernel by epilogue - 0 bias, 1 bias+GELU, 2 bias+SiLU, 3 qkv+RoPE;
+ * 4 attention, 5 row_norm, 6 the small-M (128x128 tile) GEMM kernel with any epilogue (decoder, embeddings). */
+#define NOVA_PROF_SLOTS 7
 int nova_prof_enable(int on);
 int nova_prof_collect(double* ms, double* work, long long* launches, int slots);
 

@@ -232,7 +232,7 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
                           sizeof(T) == 2 ? NOVA_BF16 : NOVA_F32, st);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(ntm * ntn), block(256);
-  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  ProfScope prof(PROF_GEMM_SMALL, 2.0 * M * N * K, st);
   const T* a = static_cast<const T*>(A);
   const T* w = static_cast<const T*>(W);
   T* c = static_cast<T*>(C);

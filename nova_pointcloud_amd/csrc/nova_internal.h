@@ -12,7 +12,8 @@ int check_launch(const char* what);
 
 // ---- optional per-kernel timing with HIP events on the launch stream (capi.hip). Slots: one per
 // kernel family; `work` = algorithmic FLOPs (or bytes) of the launch. No-ops unless enabled.
-enum { PROF_GEMM_NONE = 0, PROF_GEMM_GELU, PROF_GEMM_SILU, PROF_GEMM_ROPE, PROF_ATTN, PROF_ROWNORM, PROF_SLOTS };
+// PROF_GEMM_* : the 256x256 (large-M, encoder) GEMM kernels by epilogue; PROF_GEMM_SMALL: the 128x128 kernel, any epilogue
+enum { PROF_GEMM_NONE = 0, PROF_GEMM_GELU, PROF_GEMM_SILU, PROF_GEMM_ROPE, PROF_ATTN, PROF_ROWNORM, PROF_GEMM_SMALL, PROF_SLOTS };
 struct ProfScope {
   ProfScope(int slot, double work, hipStream_t st);
   ~ProfScope();

@@ -78,7 +78,7 @@ SIGNATURES["nova_prof_enable"] = [c_int]
 SIGNATURES["nova_debug_force_gemm_tile"] = [c_int]
 SIGNATURES["nova_prof_collect"] = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_longlong), c_int]
-PROF_SLOTS = ["gemm_bias", "gemm_bias_gelu", "gemm_bias_silu", "qkv_gemm_rope", "attention", "row_norm"]
+PROF_SLOTS = ["gemm_bias", "gemm_bias_gelu", "gemm_bias_silu", "qkv_gemm_rope", "attention", "row_norm", "gemm_small_tile"]
 PLAIN = {"nova_version": (c_int, []), "nova_last_error": (ctypes.c_char_p, []), "nova_check_device": (c_int, [])}
 
 
