@@ -227,13 +227,7 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
     return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
   const bool can256 = N % 256 == 0 && (epi != EPI_ROPE || (e.rope_cols % 256 == 0 && e.q_cols % 256 == 0));  // rotation is decided per tile
   if (g_force_tile == 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
-  // Kernel choice by rounds over the chip (tools/gemm_small_m.py): the persistent 256x256 kernel runs one tile per CU
-  // per round, the 128x128 kernel two workgroups per CU; a full round of the former takes ~1.4x a full round of the
-  // latter for 4x the work. Encoder GEMMs (thousands of tiles) and the decoder's N = 20480 AdaLN projection go to the
-  // 256 kernel, the decoder's 1024-wide GEMMs and short first-half sequences (< ~130 big tiles) to the 128 kernel.
-  const long tiles256 = (long)((M + 255) / 256) * (N / 256), tiles128 = (long)((M + BM - 1) / BM) * (N / BN);
-  const long cost256 = (tiles256 + 255) / 256 * 14, cost128 = (tiles128 + 511) / 512 * 10;
-  if (can256 && (g_force_tile == 256 || (g_force_tile == 0 && cost256 <= cost128)))
+  if (can256 && (g_force_tile == 256 || (g_force_tile == 0 && M >= 4096)))
     return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols, e.q_scale, e.q_cols,
                           sizeof(T) == 2 ? NOVA_BF16 : NOVA_F32, st);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
