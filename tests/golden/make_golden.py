@@ -63,6 +63,59 @@ class FlowMatchSampler(object):
         return type("Out", (), {"prev_sample": model_output.mul(dt).add_(sample)})
 
 
+class FlowMatchTrainer(object):
+    """RESTATED from scheduling_cfm.py:40-49,92-95,111-123 (class needs diffusers): the training side that
+    Transformer3DModel.get_losses touches (sample_timesteps, add_noise, .timestep, .config.prediction_type absent)."""
+
+    def __init__(self, num_train_timesteps=1000, shift=1.0):
+        t = np.arange(1, num_train_timesteps + 1, dtype="float32")[::-1]
+        s = t / num_train_timesteps
+        s = shift * s / (1 + (shift - 1) * s)
+        self.n = num_train_timesteps
+        self.timesteps, self.sigmas = torch.as_tensor(s * num_train_timesteps), torch.as_tensor(s.copy())
+        self.timestep = self.sigma = None
+        self.config = type("Cfg", (), {})()
+
+    def sample_timesteps(self, size, device=None):
+        dist = torch.normal(0, 1, size, device=device).sigmoid_()
+        return dist.mul_(self.n).to(dtype=torch.int64)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        dtype, device = original_samples.dtype, original_samples.device
+        self.timestep = self.timesteps.to(device=device)[timesteps]
+        self.sigma = self.sigmas.to(device=device, dtype=dtype)[timesteps]
+        self.sigma = self.sigma.view(timesteps.shape + (1,) * (noise.dim() - timesteps.dim()))
+        return self.sigma * noise + (1.0 - self.sigma) * original_samples
+
+
+TRAIN_GRADS = ["mask_embed.mask_token", "image_decoder.head.weight", "image_encoder.blocks.0.attn.qkv.weight",
+               "video_encoder.blocks.0.mlp.fc1.bias", "text_embed.proj.weight", "image_decoder.blocks.0.norm1.proj.weight"]
+
+
+def train_record(m, seed, B, image_dim, latent_hw, prompt_embeds):
+    """One training forward/backward of the reference (Transformer3DModel.train_video, transformer_3d.py:166-190):
+    loss and a few parameter gradients under fixed torch / numpy global seeds (MaskEmbed draws its ratio from
+    scipy.stats.truncnorm, TextEmbed's prompt dropout from np.random; everything else from torch's global RNG)."""
+    m.noise_scheduler = FlowMatchTrainer()
+    m.train()
+    g = torch.Generator().manual_seed(4321 + seed)
+    x = (torch.randn(B, image_dim, *latent_hw, generator=g) * 0.8).bfloat16().float()
+    torch.manual_seed(100 + seed)
+    np.random.seed(100 + seed)
+    m.zero_grad(set_to_none=True)
+    out = m({"x": x.clone(), "prompt": [p.clone() for p in prompt_embeds]})
+    out["loss"].backward()
+    grads = dict(m.named_parameters())
+    rec = {"train/x": x.numpy(), "train/loss": out["loss"].detach().double().numpy(),
+           "train/seed": np.asarray(100 + seed), "train/mask": m.mask_embed.mask.detach().numpy()}
+    for k in TRAIN_GRADS:
+        if k in grads and grads[k].grad is not None:
+            rec["train/grad/" + k] = grads[k].grad.detach().numpy().copy()
+    m.zero_grad(set_to_none=True)
+    m.eval()
+    return rec
+
+
 class Model(Transformer3DModel):
     """Transformer3DModel + the two properties diffusers' ModelMixin would provide."""
 
@@ -114,6 +167,10 @@ def make_case(name, seed, D, heads, depths, latent_hw, token_dim, token_len, rot
     g = torch.Generator().manual_seed(1234 + seed)
     lens = [int(v) for v in torch.randint(2, token_len + 1, (B,), generator=g)]
     prompt_embeds = [(torch.randn(n, token_dim, generator=g) * 0.5).bfloat16().float() for n in lens]
+
+    # the training record first: tensors the reference caches during generation are inference tensors and cannot
+    # enter autograd afterwards (abs-PE table); generation below does not depend on the global RNG state
+    train_rec = train_record(m, seed, B, image_dim, latent_hw, prompt_embeds)
 
     # RESTATED pipeline_nova.py:204-215 (prompt_embeds path, guidance > 1) on the reference's encode_prompts
     pe = m.text_embed.encode_prompts(prompt_embeds)
@@ -179,9 +236,10 @@ def make_case(name, seed, D, heads, depths, latent_hw, token_dim, token_len, rot
     arrays["out/z_last"] = trace["z"][-1].numpy()
     arrays["dec/x"], arrays["dec/t"], arrays["dec/z"] = dx.numpy(), dt.numpy(), dz.numpy()
     arrays["dec/pred_ids"], arrays["dec/out"] = dids.numpy(), dout.numpy()
+    arrays.update(train_rec)
     path = os.path.join(HERE, name + ".npz")
     np.savez(path, **arrays)
-    print(f"{name}: x {tuple(out.shape)} |x|max {out.abs().max():.4f} num_preds {num_preds.tolist()} -> {path} "
+    print(f"{name}: train loss {float(arrays['train/loss']):.6f}; x {tuple(out.shape)} |x|max {out.abs().max():.4f} num_preds {num_preds.tolist()} -> {path} "
           f"({os.path.getsize(path) / 1e6:.2f} MB)")
 
 

@@ -18,7 +18,7 @@ class Golden(object):
         self.name = name
         self.weights = {k[2:]: bf16_bits_to_f32(z[k]) for k in z.files if k.startswith("w/")}
         self.meta = {k[5:]: z[k].item() for k in z.files if k.startswith("meta/")}
-        self.t = {k: torch.from_numpy(z[k]) for k in z.files if k.split("/")[0] in ("in", "out", "dec")}
+        self.t = {k: torch.from_numpy(z[k]) for k in z.files if k.split("/")[0] in ("in", "out", "dec", "train")}
         n = len([k for k in z.files if k.startswith("in/prompt_embeds/")])
         self.prompt_embeds = [self.t[f"in/prompt_embeds/{i}"] for i in range(n)]
 

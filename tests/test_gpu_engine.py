@@ -318,3 +318,41 @@ def test_pipeline_options_on_gpu_match_cpu_module_path(hip):
             outs.append(pipe(**args).frames)
         assert outs[0].shape == outs[1].shape
         assert rel(outs[1], outs[0]) < 1e-4, kw
+
+
+@pytest.mark.gpu
+def test_training_step_on_gpu_takes_the_torch_path_and_matches_cpu(gold, hip):
+    """with grad enabled the modules must fall back to their torch definition (the HIP
+    kernels have no backward), so `train_video` trains on the GPU unchanged. The random draws of a training step
+    (mask order, prompt dropout, noise, timesteps) come from device-specific generators, so the GPU step is compared
+    with a CPU step of the same model under identical injected draws."""
+    import numpy as np
+
+    from diffnext.models import embeddings as E
+
+    def step(device):
+        model = build_from_golden(gold, device=device)
+        model.noise_scheduler = FlowMatchEulerDiscreteScheduler()
+        model.train()
+        g = torch.Generator().manual_seed(5)
+        real_rand, real_randn, real_normal = torch.rand, torch.randn, torch.normal
+        # every torch-level draw is made on the CPU generator g and moved: same numbers on both devices
+        torch.rand = lambda *a, **k: real_rand(*a, generator=g).to(k.get("device", "cpu"))
+        torch.randn = lambda *a, **k: real_randn(*a, generator=g, dtype=k.get("dtype", None)).to(k.get("device", "cpu"))
+        torch.normal = lambda m_, s_, size, **k: real_normal(m_, s_, size, generator=g).to(k.get("device", "cpu"))
+        np.random.seed(11)
+        try:
+            out = model({"x": gold.t["train/x"].clone().to(device), "prompt": [p.clone().to(device) for p in gold.prompt_embeds]})
+        finally:
+            torch.rand, torch.randn, torch.normal = real_rand, real_randn, real_normal
+        out["loss"].backward()
+        grads = {k: v.grad.detach().float().cpu() for k, v in model.named_parameters() if v.grad is not None}
+        return float(out["loss"].detach()), grads
+
+    loss_cpu, g_cpu = step("cpu")
+    loss_gpu, g_gpu = step("cuda")
+    assert abs(loss_gpu - loss_cpu) <= 2e-4 * abs(loss_cpu)
+    assert set(g_gpu) == set(g_cpu) and len(g_gpu) > 20
+    for k in g_cpu:
+        scale = g_cpu[k].abs().max()
+        assert (g_gpu[k] - g_cpu[k]).abs().max() <= 5e-3 * scale + 1e-7, k

@@ -155,3 +155,34 @@ def test_pipeline_cpu_ddpm_matches_oracle(gold):
     ref = O.generate(gold.weights, gold.oracle_config(), gold.t["in/prompt"], gold.t["in/num_preds"].numpy(), num_diffusion_steps=4,
                      guidance_scale=m["guidance"], generator=torch.Generator().manual_seed(21), ddpm=kw)
     assert (out - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
+def test_training_step_matches_reference(gold):
+    """SURVEY section 8f N2 (training through the torch definition of the same modules): one forward/backward of
+    `train_video` (reference transformer_3d.py:166-190, get_losses :79-100) under the recorded torch / numpy global
+    seeds reproduces the reference's loss, mask and parameter gradients. The fixture was produced by the reference's
+    own Transformer3DModel with the training side of its flow-matching scheduler restated (make_golden.py)."""
+    import numpy as np
+
+    model = build_from_golden(gold)
+    model.noise_scheduler = FlowMatchEulerDiscreteScheduler()
+    model.train()
+    seed = int(gold.t["train/seed"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    out = model({"x": gold.t["train/x"].clone(), "prompt": [p.clone() for p in gold.prompt_embeds]})
+    loss = out["loss"]
+    ref = float(gold.t["train/loss"])
+    assert abs(float(loss.detach()) - ref) <= 1e-5 * abs(ref)
+    assert torch.equal(model.mask_embed.mask.detach().float(), gold.t["train/mask"].float())
+    loss.backward()
+    params = dict(model.named_parameters())
+    checked = 0
+    for key, want in gold.t.items():
+        if not key.startswith("train/grad/"):
+            continue
+        got = params[key[len("train/grad/"):]].grad
+        assert got is not None and got.shape == want.shape
+        assert (got - want).abs().max() <= 2e-5 * want.abs().max() + 1e-9
+        checked += 1
+    assert checked >= 5
