@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256) void attn_f32(const float* __restrict__ q, con
   const int nkt = (Lk + F_KV - 1) / F_KV;
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // explicit: do not rely on the compiler draining LDS-DMA before a barrier
     __syncthreads();
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     const char* tk = smem + (kt & 1) * 2 * TILE;

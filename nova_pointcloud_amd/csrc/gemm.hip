@@ -101,18 +101,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
     }
   };
 
+  const int nkt = K / (ROWB / (int)sizeof(T));
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // The accumulators START at the bias (all three GEMM kernels do, so that they stay bit-identical): no add in the
+  // epilogue, where every VALU issue is paid with the matrix pipe idle.
+  f4v bv[4];
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
+  if (e.bias) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wn * 64 + nf * 16 + fg * 4);
+  }
   f4v acc[4][4];  // [nf][mf]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
-
-  const int nkt = K / (ROWB / (int)sizeof(T));
-  const int fr = lane & 15, fg = lane >> 4;
+    for (int j = 0; j < 4; ++j) acc[i][j] = bv[i];
 
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();  // tile kt landed (compiler drains vmcnt before the barrier); buffer (kt+1)&1 free
+    // tile kt landed for this wave, then for all of them; buffer (kt+1)&1 free. The wait is explicit: whether the
+    // compiler drains vmcnt for LDS-DMA before a barrier depends on what else it has in flight (with the bias loads
+    // ahead of the loop it stopped doing so).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     const char* ta = smem + (kt & 1) * 2 * TILE_BYTES;
     const char* tw = ta + TILE_BYTES;
@@ -134,13 +147,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
   // ---- epilogue: lane holds out[m][n..n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4).
   // Loads are batched (all bias vectors once, the 4 RoPE vectors of a row together) so their latencies
   // overlap instead of serialising behind per-fragment branches.
-  f4v bv[4];
-#pragma unroll
-  for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
-  if (e.bias) {
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wn * 64 + nf * 16 + fg * 4);
-  }
   const bool rot = EPI == EPI_ROPE && n0 < e.rope_cols;  // tile-uniform: rope_cols is a multiple of the tile width
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf) {
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
     T* dst = C + (size_t)m * N + n0 + wn * 64 + fg * 4;
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
-      f4v v = acc[nf][mf] + bv[nf];
+      f4v v = acc[nf][mf];
       if (EPI == EPI_GELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);

@@ -130,13 +130,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
     stage_piece(u, kt, 1);
   };
 
+  const int fr = lane & 15, fg = lane >> 4;
+  f4v bv[4];  // the accumulators start at the bias (see gemm.hip)
+#pragma unroll
+  for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
+  if (e.bias) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
+  }
   f4v acc[4][8];  // [nf][mf]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15, fg = lane >> 4;
+    for (int j = 0; j < 8; ++j) acc[i][j] = bv[i];
 
   // ---- prologue: q = 0..5 = tile 0 (A0 W1 A1 W0) + tile 1 (A0 W1); wait for tile 0
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
@@ -231,13 +237,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   if (wr == 0) NOVA_BARRIER();  // re-align the groups
 
   // ---- epilogue (same lane-local form as gemm.hip): lane holds out[m][n..n+3]
-  f4v bv[4];
-#pragma unroll
-  for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
-  if (e.bias) {
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
-  }
   const bool rot = EPI == E_ROPE && n0 < e.rope_cols;
 #pragma unroll
   for (int mf = 0; mf < 8; ++mf) {
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
     u2v pk[4];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) {
-      f4v v = acc[nf][mf] + bv[nf];
+      f4v v = acc[nf][mf];
       if (EPI == E_GELU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
@@ -386,15 +385,54 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) wf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
   };
-  auto mma_quadrant = [&](int mi, int ni, PFrag<T> (&wf)[2][2]) {
+  // The accumulators start at the bias: the first MFMA of every accumulator (k half 0 of the tile's first K-tile) takes
+  // the bias registers as its C operand, so there is neither a zeroing pass nor a bias add in the epilogue.
+  f4v bv[4];
+  auto mma_quadrant = [&](int mi, int ni, PFrag<T> (&wf)[2][2], auto first_ktile) {
+    constexpr bool FIRST = decltype(first_ktile)::value;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], acc[ni * 2 + nf][mi * 4 + mf]);
+        for (int mf = 0; mf < 4; ++mf)
+          acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], (FIRST && kk == 0) ? bv[ni * 2 + nf] : acc[ni * 2 + nf][mi * 4 + mf]);
     __builtin_amdgcn_s_setprio(0);
+  };
+  auto load_bias = [&](int n0) {
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
+    if (e.bias) {
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
+    }
+  };
+  // one K-tile: 4 phases (see the header comment)
+  auto ktile = [&](int kt, auto first_ktile) {
+    const char* buf = smem + (kt & 1) * P_BUF;
+    read_a(buf, 0);
+    read_w(buf, 0, wf0);
+    stage(2, kt + 1);
+    NOVA_BARRIER();
+    mma_quadrant(0, 0, wf0, first_ktile);
+    NOVA_BARRIER();
+    read_w(buf, 1, wf1);
+    stage(3, kt + 1);
+    NOVA_BARRIER();
+    mma_quadrant(0, 1, wf1, first_ktile);
+    NOVA_BARRIER();
+    read_a(buf, 1);
+    stage(0, kt + 2);
+    NOVA_BARRIER();
+    mma_quadrant(1, 1, wf1, first_ktile);
+    NOVA_BARRIER();
+    stage(1, kt + 2);
+    if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NOVA_BARRIER();
+    mma_quadrant(1, 0, wf0, first_ktile);
+    NOVA_BARRIER();
   };
 
   if (e.stagger > 0) {  // phase-shift the workgroups so that their epilogue store bursts do not coincide chip-wide
@@ -406,14 +444,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   auto tile_at = [&](int i) { return cbase + (e.rev ? csize - 1 - i : i); };
   tile_origin(tile_at(it), m0, n0);
   set_tile(m0, n0);
+  { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
+  load_bias(n0);  // older than the DMAs: landed when the wait below returns (in-order retirement)
   stage_prologue();
   bool first = true;
   for (;;) {
     { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = f4v{0.f, 0.f, 0.f, 0.f};
     // K-tile 0 of this tile landed: all but (tile 1: A0, W1) and, after the first tile, everything the previous
     // epilogue issued after the prologue DMAs (at least its STORES_TILE stores)
     if (nkt == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -421,39 +457,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + STORES_TILE) : "memory");
     NOVA_BARRIER();
     if (wr == 1) NOVA_BARRIER();  // group 1 runs one barrier behind group 0 inside the K loop
-    f4v bv[4];  // bias of this tile's columns: requested here, landed long before the epilogue
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
-    if (e.bias) {
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
-    }
-
-    for (int kt = 0; kt < nkt; ++kt) {
-      const char* buf = smem + (kt & 1) * P_BUF;
-      read_a(buf, 0);
-      read_w(buf, 0, wf0);
-      stage(2, kt + 1);
-      NOVA_BARRIER();
-      mma_quadrant(0, 0, wf0);
-      NOVA_BARRIER();
-      read_w(buf, 1, wf1);
-      stage(3, kt + 1);
-      NOVA_BARRIER();
-      mma_quadrant(0, 1, wf1);
-      NOVA_BARRIER();
-      read_a(buf, 1);
-      stage(0, kt + 2);
-      NOVA_BARRIER();
-      mma_quadrant(1, 1, wf1);
-      NOVA_BARRIER();
-      stage(1, kt + 2);
-      if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      NOVA_BARRIER();
-      mma_quadrant(1, 0, wf0);
-      NOVA_BARRIER();
-    }
+    ktile(0, std::true_type{});
+    for (int kt = 1; kt < nkt; ++kt) ktile(kt, std::false_type{});
     if (wr == 0) NOVA_BARRIER();  // re-align the groups: every LDS slot is dead from here on
 
     // ---- epilogue
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
     const float qmul = (EPI == E_ROPE && cn0 < e.q_cols) ? e.q_scale : 1.0f;  // tile-uniform; x * 1.0f is exact
     // four groups of 2 fragment row blocks. The next tile's prologue DMAs go out FIRST, ahead of this tile's stores in
     // the memory pipeline (issued behind them they queue for ~7k cycles). What the epilogue needs from memory before
-    // it can start (bias, the RoPE rows of groups 0-1) is therefore consumed before the DMAs are issued; the RoPE rows
+    // it can start (the RoPE rows of groups 0-1) is therefore consumed before the DMAs are issued; the RoPE rows
     // of groups 2-3 are requested after them and arrive behind them (in-order retirement), by which time they are done.
     f4v cs[4][2][4];  // [group][row block][nf]
     int coff[4];      // column of this lane's 4 floats inside a table row (head-relative), per nf
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
         u2v pk[4];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-          f4v v = acc[nf][mf] + bv[nf];
+          f4v v = acc[nf][mf];
           if (EPI == E_GELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = sizeof(T) == 2 ? gelu_erf_fast(v[q]) : gelu_erf(v[q]);
@@ -539,13 +544,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
     };
     auto next_prologue = [&]() {
       if (more) {
-        tile_origin(tile_at(nxt), m0, n0);
         set_tile(m0, n0);
         stage_prologue();
       }
     };
+    // the next tile's origin and its bias first: the bias loads are older than everything else this epilogue issues
+    // and have landed when the wait at the next tile top returns
+    if (more) {
+      tile_origin(tile_at(nxt), m0, n0);
+      if (!rot) load_bias(n0);  // (rotating tiles: after groups 0-1, when 64 accumulator registers are free)
+    }
     // the rotation is tile-uniform (decided per 256-column tile): two straight-line epilogues behind one scalar branch
-    asm volatile("" ::"v"(bv[3]));  // the compiler's wait for the bias sits here, before the DMAs
     if (rot) {
       load_cs(0);
       load_cs(1);
@@ -554,6 +563,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
       finish_group(0, std::true_type{});
       finish_group(1, std::true_type{});
       __builtin_amdgcn_sched_barrier(0);  // keep the later groups' table loads below groups 0-1 (register budget)
+      if (more) load_bias(n0);
       load_cs(2);
       load_cs(3);
       finish_group(2, std::true_type{});
