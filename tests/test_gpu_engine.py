@@ -299,6 +299,26 @@ def test_image_like_geometry_patch2_matches_oracle(hip, rotary):
     assert rel(out, ref) < 1e-4
 
 
+@pytest.mark.parametrize("latent,B,K,guidance", [((6, 10), 3, 7, 4.0), ((10, 14), 5, 9, 1.0), ((2, 2), 1, 4, 5.0)])
+def test_odd_geometries_and_batches_match_oracle(hip, latent, B, K, guidance):
+    """Ragged everything: token counts that are no multiple of any tile (60, 140, 4), conditioning grids of 15 / 35 / 1
+    tokens, odd batches (uneven lanes), more AR steps than some steps have tokens, guidance on and off (single pass),
+    prompts of different lengths - HIP f32 against the oracle from the same seed."""
+    model, sd, cfg = _tiny_model(128, 2, latent, image_dim=3, stride=16, rotary=True, seed=11)
+    g = torch.Generator().manual_seed(21)
+    prompts = [torch.randn(1 + (3 * i) % 8, 64, generator=g) * 0.5 for i in range(B)]
+    pipe = NOVAPipeline(transformer=model.cuda(), scheduler=FlowMatchEulerDiscreteScheduler())
+    out = pipe(prompt_embeds=[p.cuda() for p in prompts], num_inference_steps=K, num_diffusion_steps=3, guidance_scale=guidance,
+               generator=torch.Generator().manual_seed(6), output_type="latent", disable_progress_bar=True).frames
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 8)
+    prompt = prompt if guidance > 1 else prompt[:B]  # single pass: conditional rows only
+    ref = O.generate(sd, cfg, prompt, O.cosine_schedule(latent[0] * latent[1], K), num_diffusion_steps=3,
+                     guidance_scale=guidance, generator=torch.Generator().manual_seed(6))
+    assert out.shape == ref.shape == (B, 3, 1) + tuple(latent)
+    assert torch.isfinite(out).all()
+    assert rel(out, ref) < 1e-4
+
+
 def test_pipeline_options_on_gpu_match_cpu_module_path(hip):
     """num_images_per_prompt, negative_prompt_embeds, guidance <= 1 (single pass), more AR steps than tokens:
     the HIP engine against this package's own PyTorch module path (itself pinned to the reference on the goldens)."""
