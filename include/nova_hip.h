@@ -68,6 +68,16 @@ int nova_debug_force_gemm_tile(int tile);
 int nova_gemm_bias_act(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                        int dtype, void* stream);
 
+/* ---- MX-fp8 projection GEMM (BASELINE configs[4]: d48w1536 "fp8 MFMA path"; the reference has no fp8 path, so this is
+ * compared with the bf16 result of the same layer) ---------------------------------------------
+ * nova_quantize_rows_fp8: per-row dynamic quantisation of bf16 rows to OCP e4m3, scale[r] = max|x[r]| / 448.
+ * nova_gemm_fp8_bias_act: out_bf16[M,N] = act((A8[M,K] . W8[N,K]^T) * a_scale[m] * w_scale[n] + bias[n]) on
+ * v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales); N % 256 == 0, K % 128 == 0. Replaces the same nn.Linear
+ * calls as nova_gemm_bias_act (vision_transformer.py:33-38,64) with quantised operands. */
+int nova_quantize_rows_fp8(const void* x_bf16, void* out_fp8, float* scale, long long rows, int D, void* stream);
+int nova_gemm_fp8_bias_act(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const float* bias,
+                           void* out_bf16, int M, int N, int K, int act, void* stream);
+
 /* ---- fused QKV projection + 3-D RoPE -------------------------------------------------------
  * qkv[S*L, 3D] = x[S*L, D] * Wqkv^T + b, then q and k (columns [0, 2D)) rotated pairwise with
  * rope[(s % rope_batch), l, pair] = (cos, sin). rope == NULL: no rotation (abs-PE models).

@@ -127,6 +127,18 @@ int nova_gemm_bias_act(const void* A, const void* W, const float* bias, void* ou
   return gemm_bias_act(A, W, bias, out, M, N, K, act, dtype, (hipStream_t)stream);
 }
 
+int nova_quantize_rows_fp8(const void* x, void* out, float* scale, long long rows, int D, void* stream) {
+  NOVA_REQUIRE(rows <= 0 || (x && out && scale), NOVA_ERR_ARG, "quantize_rows_fp8: null pointer");
+  return quantize_rows_fp8(x, out, scale, (long)rows, D, (hipStream_t)stream);
+}
+
+int nova_gemm_fp8_bias_act(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const float* bias,
+                           void* out, int M, int N, int K, int act, void* stream) {
+  NOVA_REQUIRE(M <= 0 || (A8 && a_scale && W8 && w_scale && out), NOVA_ERR_ARG, "gemm_fp8: null pointer");
+  NOVA_REQUIRE(act >= NOVA_ACT_NONE && act <= NOVA_ACT_SILU, NOVA_ERR_ARG, "gemm_fp8: bad activation %d", act);
+  return gemm256_fp8_launch(A8, a_scale, W8, w_scale, bias, out, M, N, K, act, (hipStream_t)stream);
+}
+
 int nova_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L, int D,
                   int heads, int rope_batch, int dtype, void* stream) {
   NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "qkv_rope: bad dtype %d", dtype);

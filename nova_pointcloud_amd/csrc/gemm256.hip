@@ -43,6 +43,8 @@ struct GemmEpi256 {
   int q_cols;
   int gm;  // row panels per tile group (L2 reuse shape)
   int rev;      // persistent form: walk each XCD's chunk of the tile list back to front (xcd_remap_dir, common.h)
+  const float* sa;  // fp8 path: per-row dequantisation scale of A [M]
+  const float* sw;  // fp8 path: per-row (output column) dequantisation scale of W [N]
   int stagger;  // persistent form: start delay of the last workgroup in cycles (0 = none), see gemm256p_kernel
 };
 
@@ -51,6 +53,11 @@ enum { E_NONE = 0, E_GELU = 1, E_SILU = 2, E_ROPE = 3 };
 template <typename T> struct PFrag;
 template <> struct PFrag<bf16_t> { bf8v v; };
 template <> struct PFrag<float> { f4v v; };
+typedef uint8_t fp8_t;  // OCP e4m3 storage (MX-fp8 path: 128 elements per 128-byte K-tile row)
+template <> struct PFrag<fp8_t> { u4v v; };
+typedef __attribute__((ext_vector_type(8))) int i8v;
+template <typename T> struct OutOf { typedef T type; };
+template <> struct OutOf<fp8_t> { typedef bf16_t type; };  // fp8 operands produce bf16 results
 
 __device__ __forceinline__ f4v pmma(const PFrag<bf16_t>& w, const PFrag<bf16_t>& a, f4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, c, 0, 0, 0);
@@ -303,9 +310,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 // load issued after them could only be consumed once they have all landed.
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ A, const T* __restrict__ W,
-                                                          T* __restrict__ C, int M, int N, int K, int ntm, int ntn,
-                                                          GemmEpi256 e) {
-  constexpr int STORES_TILE = sizeof(T) == 2 ? 16 : 32;  // global stores a wave issues per tile epilogue
+                                                          typename OutOf<T>::type* __restrict__ C, int M, int N, int K,
+                                                          int ntm, int ntn, GemmEpi256 e) {
+  typedef typename OutOf<T>::type OT;
+  constexpr bool FP8 = sizeof(T) == 1;
+  constexpr int STORES_TILE = sizeof(OT) == 2 ? 16 : 32;  // global stores a wave issues per tile epilogue
   __shared__ __attribute__((aligned(16))) char smem[P_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -391,19 +400,34 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   auto mma_quadrant = [&](int mi, int ni, PFrag<T> (&wf)[2][2], auto first_ktile) {
     constexpr bool FIRST = decltype(first_ktile)::value;
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    if constexpr (FP8) {
+      // MX-fp8: ONE v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator and K-tile (twice the bf16 rate). A lane's 32 operand
+      // bytes are the two 16-byte chunks (fg, fg + 4) it reads anyway - the same (lane, byte) -> k map on both operands,
+      // which is all a contraction needs. Block scales are 1 (e8m0 127); the per-row scales are applied in the epilogue.
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf)
-          acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], (FIRST && kk == 0) ? bv[ni * 2 + nf] : acc[ni * 2 + nf][mi * 4 + mf]);
+        for (int mf = 0; mf < 4; ++mf) {
+          const i8v wv = __builtin_bit_cast(i8v, __builtin_shufflevector(wf[nf][0].v, wf[nf][1].v, 0, 1, 2, 3, 4, 5, 6, 7));
+          const i8v av = __builtin_bit_cast(i8v, __builtin_shufflevector(af[mf][0].v, af[mf][1].v, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[ni * 2 + nf][mi * 4 + mf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              wv, av, FIRST ? bv[ni * 2 + nf] : acc[ni * 2 + nf][mi * 4 + mf], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+          for (int mf = 0; mf < 4; ++mf)
+            acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], (FIRST && kk == 0) ? bv[ni * 2 + nf] : acc[ni * 2 + nf][mi * 4 + mf]);
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   auto load_bias = [&](int n0) {
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
-    if (e.bias) {
+    if (!FP8 && e.bias) {  // fp8: accumulators start at zero, the scales multiply the raw sums (bias added below)
 #pragma unroll
       for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
     }
@@ -473,6 +497,19 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
     // the memory pipeline (issued behind them they queue for ~7k cycles). What the epilogue needs from memory before
     // it can start (the RoPE rows of groups 0-1) is therefore consumed before the DMAs are issued; the RoPE rows
     // of groups 2-3 are requested after them and arrive behind them (in-order retirement), by which time they are done.
+    // fp8: out = acc * sa[row] * sw[col] + bias[col]; the three vectors are requested first and consumed before the DMAs
+    f4v swv[4], bfv[4];
+    float sav[8];
+    if constexpr (FP8) {
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf) {
+        swv[nf] = *reinterpret_cast<const f4v*>(e.sw + cn0 + wc * 64 + nf * 16 + fg * 4);
+        bfv[nf] = e.bias ? *reinterpret_cast<const f4v*>(e.bias + cn0 + wc * 64 + nf * 16 + fg * 4) : f4v{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int mf = 0; mf < 8; ++mf) sav[mf] = e.sa[min(cm0 + wr * 128 + mf * 16 + fr, M - 1)];
+      asm volatile("" ::"v"(sav[7]));  // youngest of them: the compiler's wait sits here (loads retire in order)
+    }
     f4v cs[4][2][4];  // [group][row block][nf]
     int coff[4];      // column of this lane's 4 floats inside a table row (head-relative), per nf
     if (rot) {
@@ -508,9 +545,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
           f4v v = acc[nf][mf];
+          if constexpr (FP8) v = (v * sav[mf]) * swv[nf] + bfv[nf];
           if (EPI == E_GELU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = sizeof(T) == 2 ? gelu_erf_fast(v[q]) : gelu_erf(v[q]);
+            for (int q = 0; q < 4; ++q) v[q] = sizeof(OT) == 2 ? gelu_erf_fast(v[q]) : gelu_erf(v[q]);
           } else if (EPI == E_SILU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
@@ -525,13 +563,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
             }
             v = v * qmul;
           }
-          if constexpr (sizeof(T) == 2) {
+          if constexpr (sizeof(OT) == 2) {
             pk[nf] = u2v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
           } else {
             *reinterpret_cast<f4v*>(C + (size_t)m * N + cn0 + wc * 64 + fg * 4 + nf * 16) = v;
           }
         }
-        if constexpr (sizeof(T) == 2) {  // 16-byte stores through v_permlane16_swap, as in the kernel above
+        if constexpr (sizeof(OT) == 2) {  // 16-byte stores through v_permlane16_swap, as in the kernel above
 #pragma unroll
           for (int pr = 0; pr < 2; ++pr) {
             const auto lo = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
@@ -639,6 +677,28 @@ static int launch256p(const void* A, const void* W, void* C, int M, int N, int K
   return check_launch("gemm256p");
 }
 
+// MX-fp8 operands (OCP e4m3 bytes, K % 128 == 0), bf16 result; persistent kernel only. Internal entry for capi.hip.
+int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, void* C, int M,
+                       int N, int K, int epi, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (N % 256 != 0 || K % 128 != 0 || K <= 0) return set_error(NOVA_ERR_SHAPE, "gemm_fp8: need N %% 256 == 0 and K %% 128 == 0 (got N=%d K=%d)", N, K);
+  if (epi == E_ROPE) return set_error(NOVA_ERR_ARG, "gemm_fp8: no RoPE epilogue");
+  GemmEpi256 e{bias, nullptr, 1, 1, 1, 0, 1.0f, 0, g_gm256, walk_is_reverse() ? 1 : 0, sa, sw, 0};
+  const int ntm = (M + 255) / 256, ntn = N / 256;
+  dim3 grid(cu_slots()), block(512);
+  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  const fp8_t* a = static_cast<const fp8_t*>(A8);
+  const fp8_t* w = static_cast<const fp8_t*>(W8);
+  bf16_t* c = static_cast<bf16_t*>(C);
+  switch (epi) {
+    case E_NONE: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_GELU: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_SILU: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    default: return set_error(NOVA_ERR_ARG, "gemm_fp8: unknown epilogue %d", epi);
+  }
+  return check_launch("gemm256p fp8");
+}
+
 template <typename T>
 static int launch256(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
                      hipStream_t st) {
@@ -660,7 +720,7 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
                    hipStream_t st) {
-  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, walk_is_reverse() ? 1 : 0, g_stagger256};
+  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, walk_is_reverse() ? 1 : 0, nullptr, nullptr, g_stagger256};
   return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st) : launch256<float>(A, W, C, M, N, K, epi, e, st);
 }
 

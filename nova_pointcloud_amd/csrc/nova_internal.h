@@ -66,6 +66,9 @@ int build_sequence(const void* prefix, long prefix_seq_rows, const void* tokens,
                    const long long* ids, void* x, int S, int B, int Lp, int n_sel, int D, int dtype, hipStream_t st);
 int scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B, int Lp, int N, int n_prev, int D,
                    int dtype, hipStream_t st);
+int quantize_rows_fp8(const void* x, void* out, float* scale, long rows, int D, hipStream_t st);
+int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, void* C, int M,
+                       int N, int K, int epi, hipStream_t st);
 int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, hipStream_t st);
 int timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, hipStream_t st);
 int patch_embed_rows(const float* x, const void* w, const float* bias, void* out, int S, int B, int n, int P, int D,

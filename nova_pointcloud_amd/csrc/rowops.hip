@@ -327,6 +327,62 @@ __global__ __launch_bounds__(256) void silu_add_rows_kernel(const T* __restrict_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MX-fp8 path (BASELINE configs[4]): per-row dynamic quantisation of bf16 activations to OCP e4m3.
+//   scale[r] = max|x[r][:]| / 448 (1 for an all-zero row), out[r][d] = e4m3(x[r][d] / scale[r])
+// One wave per row, 16-byte loads, 8-byte stores; D % 8 == 0, D <= 8192.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ out,
+                                                                float* __restrict__ scale, long rows, int D) {
+  using C = Chunk<bf16_t>;
+  constexpr int NIT = 16;
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* in = x + row * D;
+  C v[NIT];
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int d = (it * 64 + lane) * 8;
+    if (d < D) {
+      v[it] = C::load(in + d);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(v[it].v[k][j]));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int d = (it * 64 + lane) * 8;
+    if (d < D) {
+      u2v o;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[it].v[k][0] * inv, v[it].v[k][1] * inv, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[it].v[k][2] * inv, v[it].v[k][3] * inv, w, true);
+        o[k] = (uint32_t)w;
+      }
+      *reinterpret_cast<u2v*>(out + row * D + d) = o;
+    }
+  }
+}
+
+int quantize_rows_fp8(const void* x, void* out, float* scale, long rows, int D, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (D % 8 != 0 || D > 8192) return set_error(NOVA_ERR_SHAPE, "quantize_rows_fp8: need D %% 8 == 0 and D <= 8192 (got %d)", D);
+  hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, (uint8_t*)out, scale,
+                     rows, D);
+  return check_launch("quantize_rows_fp8");
+}
+
 int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, hipStream_t st) {
   if (rows <= 0) return 0;
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "silu_add_rows: D %% 4 != 0");

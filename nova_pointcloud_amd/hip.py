@@ -58,6 +58,8 @@ class SamplerStep(ctypes.Structure):
 SIGNATURES = {
     "nova_gemm_bias_act": [c_void_p] * 4 + [c_int] * 5 + [c_void_p],
     "nova_qkv_rope": [c_void_p] * 5 + [c_int] * 6 + [c_void_p],
+    "nova_quantize_rows_fp8": [c_void_p] * 3 + [ctypes.c_longlong, c_int, c_void_p],
+    "nova_gemm_fp8_bias_act": [c_void_p] * 6 + [c_int] * 4 + [c_void_p],
     "nova_qkv_rope_cols": [c_void_p] * 5 + [c_int] * 8 + [c_void_p],
     "nova_rope_table": [c_void_p] * 3 + [c_int] * 5 + [c_void_p, c_void_p],
     "nova_attn_fwd": [c_void_p] * 4 + [c_int] * 5 + [c_long] * 3 + [c_float, c_int, c_void_p],
@@ -174,6 +176,25 @@ def qkv_rope(x, w, bias, rope, S, L, heads, out=None):
         assert rope.shape[1] == L and rope.shape[2] * 2 == D // heads
     call("nova_qkv_rope", ptr(x), ptr(w), ptr(bias, torch.float32), ptr(rope, torch.float32), ptr(out),
          S, L, D, heads, nb, dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def quantize_rows_fp8(x):
+    """Per-row dynamic quantisation of bf16 rows [rows, D] to OCP e4m3 bytes + f32 row scales (amax / 448)."""
+    rows, D = x.shape
+    q = torch.empty(rows, D, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("nova_quantize_rows_fp8", ptr(x, torch.bfloat16), ptr(q), ptr(scale), rows, D, stream_ptr())
+    return q, scale
+
+
+def gemm_fp8_bias_act(a8, a_scale, w8, w_scale, bias, act=0, out=None):
+    """bf16 out[M,N] = act((a8 . w8^T) * a_scale[m] * w_scale[n] + bias); a8 [M,K], w8 [N,K] e4m3 bytes (uint8 views)."""
+    M, K = a8.shape
+    N = w8.shape[0]
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a8.device) if out is None else out
+    call("nova_gemm_fp8_bias_act", ptr(a8), ptr(a_scale, torch.float32), ptr(w8), ptr(w_scale, torch.float32),
+         ptr(bias, torch.float32), ptr(out), M, N, K, act, stream_ptr())
     return out
 
 

@@ -328,3 +328,57 @@ def test_gemm_256_tile_race_screen(hip, force_tile, form):
             out = hip.gemm_bias_act(a, w, None, 0)
             assert torch.equal(out, ref)
         del a, w, ref, out
+
+
+# ---------------------------------------------------------------------------------------------
+# MX-fp8 path (BASELINE configs[4]): quantisation + block-scaled MFMA GEMM. The reference has no fp8 path
+# (SURVEY section 8d-iv): the kernels are checked against exact arithmetic on the SAME quantised operands, and
+# the quantisation error itself is reported against the bf16 GEMM.
+# ---------------------------------------------------------------------------------------------
+def _dequant(q, scale):
+    return q.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+@pytest.mark.parametrize("rows,D", [(1, 128), (37, 1024), (513, 1536), (4096, 4096)])
+def test_quantize_rows_fp8(hip, rows, D):
+    x = rnd(rows, D, dtype=torch.bfloat16, seed=61)
+    x[0, :] = 0 if rows > 1 else x[0, :]  # an all-zero row must not divide by zero
+    q, scale = hip.quantize_rows_fp8(x)
+    amax = x.float().abs().amax(1)
+    want_scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(scale, want_scale, rtol=1e-6, atol=0)
+    want = (x.float() / scale[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    got = q.view(torch.float8_e4m3fn)
+    # same OCP e4m3 rounding as torch (round to nearest even), allowing the last bit on ties of the f32 division
+    diff = (got.float() - want.float()).abs()
+    assert (diff <= want.float().abs() * 2.0 ** -3 + 2.0 ** -9).all()
+    assert (got.float() == want.float()).float().mean() > 0.999
+    assert relerr(_dequant(q, scale), x.float()) < 0.07
+
+
+@pytest.mark.parametrize("M,N,K,act", [(256, 256, 128, 0), (300, 512, 384, 1), (5000, 1024, 1024, 2), (4096 + 77, 768, 3072, 0)])
+def test_gemm_fp8_exact_on_quantised_operands(hip, M, N, K, act):
+    a, w = rnd(M, K, dtype=torch.bfloat16, seed=71), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=72)
+    bias = rnd(N, seed=73)
+    a8, sa = hip.quantize_rows_fp8(a)
+    w8, sw = hip.quantize_rows_fp8(w)
+    out = hip.gemm_fp8_bias_act(a8, sa, w8, sw, bias, act)
+    assert out.shape == (M, N) and out.dtype == torch.bfloat16
+    ref = _dequant(a8, sa).double() @ _dequant(w8, sw).double().T + bias.double()
+    ref = [lambda x: x, torch.nn.functional.gelu, torch.nn.functional.silu][act](ref).float()
+    assert relerr(out, ref) < tol(torch.bfloat16)          # the kernel: f32 accumulation of exact products
+    full = a.float() @ w.float().T + bias
+    full = [lambda x: x, torch.nn.functional.gelu, torch.nn.functional.silu][act](full)
+    rms = ((out.float() - full).pow(2).mean() / full.pow(2).mean()).sqrt().item()
+    assert rms < 0.06, rms                                  # quantisation error of per-row e4m3 against the bf16 layer
+
+
+def test_gemm_fp8_layout_asymmetric(hip):
+    """A = I (exact in e4m3) against an asymmetric integer W: catches a wrong operand byte order or transposed C."""
+    K = N = 256
+    a = torch.eye(K, device=DEV, dtype=torch.bfloat16)
+    w = ((torch.arange(N, device=DEV)[:, None] * 3 + torch.arange(K, device=DEV)[None, :] * 5) % 13 - 6).to(torch.bfloat16)
+    a8, sa = hip.quantize_rows_fp8(a)
+    w8, sw = hip.quantize_rows_fp8(w)
+    out = hip.gemm_fp8_bias_act(a8, sa, w8, sw, None, 0)
+    assert relerr(out, _dequant(w8, sw).T.contiguous()) < 1e-2
