@@ -94,7 +94,7 @@ int nova_check_device(void) {
 }
 
 int nova_debug_force_gemm_tile(int tile) {
-  NOVA_REQUIRE(tile == 0 || tile == 128 || tile == 256 || (tile >= 2560 && tile <= 2580) || (tile >= 7001 && tile <= 7064) || (tile >= 30000 && tile < 31000) || (tile >= 40000 && tile <= 40512) || tile == 50000 || tile == 50001 || tile == 9100 || tile == 9101, NOVA_ERR_ARG, "force_gemm_tile: 0, 128, 256 or 2560+variant");
+  NOVA_REQUIRE(tile == 0 || tile == 128 || tile == 256 || (tile >= 2560 && tile <= 2580) || (tile >= 7001 && tile <= 7064) || (tile >= 30000 && tile < 31000) || (tile >= 40000 && tile <= 40512) || tile == 50000 || tile == 50001, NOVA_ERR_ARG, "force_gemm_tile: 0, 128, 256 or 2560+variant");
   gemm_force_tile(tile);
   return 0;
 }

@@ -21,6 +21,7 @@ namespace nova {
 
 constexpr int BM = 128, BN = 128, ROWB = 128;       // ROWB: bytes of K per tile row
 constexpr int TILE_BYTES = BM * ROWB;               // 16 KiB per operand tile
+constexpr int GEMM_LDS = 4 * TILE_BYTES;            // A,W x 2 buffers = 64 KiB
 
 struct GemmEpi {
   const float* bias;     // [N] or nullptr
@@ -58,14 +59,11 @@ __device__ __forceinline__ Frag<T> lds_frag(const char* tile, int row, int chunk
   return f;
 }
 
-// NST = 2: double buffer, 64 KiB LDS, two workgroups per CU. NST = 4: four K-tiles in a ring (128 KiB, one workgroup per
-// CU) with counted vmcnt waits - for launches that put at most one workgroup on a CU anyway (the decoder's GEMMs at a
-// few thousand rows), where the K loop is a chain of exposed L2 latencies rather than matrix work.
-template <typename T, int EPI, int NST>
-__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
-                                                                      T* __restrict__ C, int M, int N, int K, int ntm,
-                                                                      int ntn, GemmEpi e) {
-  __shared__ __attribute__((aligned(16))) char smem[NST * 2 * TILE_BYTES];
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                       T* __restrict__ C, int M, int N, int K, int ntm,
+                                                       int ntn, GemmEpi e) {
+  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
 
@@ -80,30 +78,26 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_kernel(const T* __
   const int tn = (t % per_group) / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- staging: wave w owns LDS-DMA pieces 4w..4w+3 (8 rows x 128 B each) of A and W. Scalar tile bases + 32-bit lane
-  // offsets (glds16: the load is invisible to the compiler's wait bookkeeping, every wait below is explicit).
+  // ---- staging addresses: wave w owns LDS-DMA pieces 4w..4w+3 (8 rows x 128 B each) of A and W
   const int rr = lane >> 3, cp = lane & 7;
+  const char* a_src[4];
+  const char* w_src[4];
   const size_t rowbytes = (size_t)K * sizeof(T);
-  const char* a_base = reinterpret_cast<const char*>(A) + (size_t)m0 * rowbytes;
-  const char* w_base = reinterpret_cast<const char*>(W) + (size_t)n0 * rowbytes;
-  uint32_t a_off[4], w_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (wid * 4 + i) * 8 + rr;                 // row inside the tile
-    const uint32_t c = (uint32_t)((cp ^ ((row >> 1) & 7)) << 4);  // logical 16-B chunk this lane fetches
-    a_off[i] = (uint32_t)min(row, M - 1 - m0) * (uint32_t)rowbytes + c;  // clamp: rows past M are never stored
-    w_off[i] = (uint32_t)row * (uint32_t)rowbytes + c;
+    const int c = cp ^ ((row >> 1) & 7);                    // logical 16-B chunk this lane fetches
+    const int am = min(m0 + row, M - 1);                    // clamp: rows past M are never stored
+    a_src[i] = reinterpret_cast<const char*>(A) + (size_t)am * rowbytes + c * 16;
+    w_src[i] = reinterpret_cast<const char*>(W) + (size_t)(n0 + row) * rowbytes + c * 16;
   }
-  const int wid_u = __builtin_amdgcn_readfirstlane(wid);
   auto stage = [&](int buf, int kt) {
-    char* la = smem + buf * 2 * TILE_BYTES + wid_u * 4096;
+    char* la = smem + buf * 2 * TILE_BYTES + wid * 4096;
     char* lw = la + TILE_BYTES;
-    const char* ab = a_base + (size_t)kt * ROWB;
-    const char* wb = w_base + (size_t)kt * ROWB;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      glds16(ab, a_off[i], la + i * 1024);
-      glds16(wb, w_off[i], lw + i * 1024);
+      __builtin_amdgcn_global_load_lds(a_src[i] + (size_t)kt * ROWB, NOVA_LDS_PTR(la + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(w_src[i] + (size_t)kt * ROWB, NOVA_LDS_PTR(lw + i * 1024), 16, 0, 0);
     }
   };
 
@@ -125,20 +119,15 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void gemm_kernel(const T* __
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = bv[i];
 
-  // ring of NST K-tiles: tile kt lives in buffer kt % NST; NST - 1 tiles are in flight ahead of the one being read
-#pragma unroll
-  for (int sidx = 0; sidx < NST - 1; ++sidx)
-    if (sidx < nkt) stage(sidx, sidx);
+  stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
-    // tile kt landed for this wave (everything but the 8 LDS-DMA instructions of each younger tile in flight), then -
-    // barrier - for all of them; the same barrier frees buffer (kt - 1) % NST for the tile issued right after it
-    const int younger = min(NST - 2, nkt - 1 - kt);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile kt landed for this wave, then for all of them; buffer (kt+1)&1 free. The wait is explicit: whether the
+    // compiler drains vmcnt for LDS-DMA before a barrier depends on what else it has in flight (with the bias loads
+    // ahead of the loop it stopped doing so).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + NST - 1 < nkt) stage((kt + NST - 1) % NST, kt + NST - 1);
-    const char* ta = smem + (kt % NST) * 2 * TILE_BYTES;
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    const char* ta = smem + (kt & 1) * 2 * TILE_BYTES;
     const char* tw = ta + TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -210,13 +199,8 @@ void gemm256_set_gm(int g);
 void gemm256_set_stagger(int cycles);
 void gemm256_set_grid(int n);
 void walk_set_alternate(int on);
-static int g_ring128 = 1;  // 0: always the double-buffered 128 kernel (A/B: nova_debug_force_gemm_tile(9100 / 9101))
 static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
 void gemm_force_tile(int tile) {
-  if (tile == 9100 || tile == 9101) {
-    g_ring128 = tile - 9100;
-    return;
-  }
   if (tile == 50000 || tile == 50001) {  // alternate the walk direction between launches of a block (off / on)
     walk_set_alternate(tile - 50000);
     return;
@@ -254,22 +238,15 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
                           sizeof(T) == 2 ? NOVA_BF16 : NOVA_F32, st);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(ntm * ntn), block(256);
-  // at most one workgroup per CU anyway: take the whole LDS for a 4-deep K ring (latency-bound small launches)
-  const bool ring = g_ring128 && ntm * ntn <= 256 && K / kelems >= 4;
   ProfScope prof(PROF_GEMM_SMALL, 2.0 * M * N * K, st);
   const T* a = static_cast<const T*>(A);
   const T* w = static_cast<const T*>(W);
   T* c = static_cast<T*>(C);
   switch (epi) {
-#define NOVA_GEMM_LAUNCH(EPI_)                                                                                       \
-  if (ring) hipLaunchKernelGGL((gemm_kernel<T, EPI_, 4>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e);        \
-  else hipLaunchKernelGGL((gemm_kernel<T, EPI_, 2>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e);             \
-  break;
-    case EPI_NONE: NOVA_GEMM_LAUNCH(EPI_NONE)
-    case EPI_GELU: NOVA_GEMM_LAUNCH(EPI_GELU)
-    case EPI_SILU: NOVA_GEMM_LAUNCH(EPI_SILU)
-    case EPI_ROPE: NOVA_GEMM_LAUNCH(EPI_ROPE)
-#undef NOVA_GEMM_LAUNCH
+    case EPI_NONE: hipLaunchKernelGGL((gemm_kernel<T, EPI_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case EPI_GELU: hipLaunchKernelGGL((gemm_kernel<T, EPI_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case EPI_SILU: hipLaunchKernelGGL((gemm_kernel<T, EPI_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case EPI_ROPE: hipLaunchKernelGGL((gemm_kernel<T, EPI_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     default: return set_error(NOVA_ERR_ARG, "gemm: unknown epilogue %d", epi);
   }
   return check_launch("gemm");

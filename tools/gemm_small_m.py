@@ -24,10 +24,8 @@ for (N, K, act, Ms) in cases:
         out = torch.empty(M, N, dtype=dt, device="cuda")
         res = {}
         for r in range(3):
-            for tile in (128, 1284, 2580):  # 128: double-buffered 128 kernel, 1284: its 4-deep ring form, 2580: persistent 256
-                hip.call("nova_debug_force_gemm_tile", 9100 + (tile == 1284))
-                hip.call("nova_debug_force_gemm_tile", 128 if tile == 1284 else tile)
+            for tile in (128, 2580):
+                hip.call("nova_debug_force_gemm_tile", tile)
                 res.setdefault(tile, []).append(timeit(lambda: hip.gemm_bias_act(a, w, bias, act, out=out), iters=10, warm=2))
         print(f"N={N} K={K} act={act} M={M}: " + "  ".join(f"{t}: {min(v) * 1e3:7.1f} us {2.0 * M * N * K / min(v) / 1e9:5.0f} TF" for t, v in res.items()), flush=True)
-hip.call("nova_debug_force_gemm_tile", 9101)
 hip.call("nova_debug_force_gemm_tile", 0)
