@@ -1,8 +1,8 @@
-"""Adaptive LayerNorm layers (reference diffnext/models/normalization.py:24-46).
+"""Adaptive LayerNorm layers: the module surface of reference diffnext/models/normalization.py:24-46.
 
-state_dict keys: `proj.{weight,bias}` (+ `lora.weight` when rank is set). On the MI355X inference
-path these layers are never called one by one: the engine concatenates every block's `proj` into
-a single [(3*depth+2)D, D] GEMM per diffusion step and fuses the modulation into `nova_row_norm`.
+state_dict keys: `proj.{weight,bias}` (+ `lora.weight` when a rank is given). On the MI355X inference path these
+layers are never called one by one: the engine concatenates every block's `proj` into a single
+[(3 * depth + 2) D, D] GEMM per diffusion step and fuses the modulation into `nova_row_norm`.
 """
 from typing import Tuple
 
@@ -10,21 +10,34 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .. import _torch_ops as ops
+
 
 class AdaLayerNormZero(nn.Module):
-    """LN (no affine) modulated by statistics regressed from a condition; extra stats are returned."""
+    """Affine-free LayerNorm whose scale and shift are regressed from a condition z.
+
+    `proj(lora(SiLU(z)))` yields `num_stats` chunks of width `dim`: the first two modulate, the rest (gates) are
+    handed back to the caller.
+    """
 
     def __init__(self, dim, rank=None, num_stats=2, eps=1e-6):
         super().__init__()
-        self.lora = nn.Linear(dim, rank, bias=False) if rank else nn.Identity()
-        self.proj = nn.Linear(rank if rank else dim, num_stats * dim)
+        self.num_stats = num_stats
+        self.activation = nn.SiLU()
+        if rank:
+            self.lora = nn.Linear(dim, rank, bias=False)
+            self.proj = nn.Linear(rank, num_stats * dim)
+        else:
+            self.lora = nn.Identity()
+            self.proj = nn.Linear(dim, num_stats * dim)
         self.norm = nn.LayerNorm(dim, eps, elementwise_affine=False) if eps else nn.Identity()
-        self.activation, self.num_stats = nn.SiLU(), num_stats
+
+    def statistics(self, z):
+        return self.proj(self.lora(F.silu(z))).chunk(self.num_stats, dim=-1)
 
     def forward(self, x, z) -> Tuple[torch.Tensor, Tuple[torch.Tensor]]:
-        stats = self.proj(self.lora(F.silu(z))).chunk(self.num_stats, dim=-1)
-        scale, shift = stats[0], stats[1]
-        return self.norm(x) * (1 + scale) + shift, stats[2:]
+        scale, shift, *rest = self.statistics(z)
+        return ops.adaln_modulate(self.norm(x), scale, shift), tuple(rest)
 
 
 class AdaLayerNorm(AdaLayerNormZero):
@@ -34,4 +47,5 @@ class AdaLayerNorm(AdaLayerNormZero):
         super().__init__(dim, rank, num_stats=2, eps=eps)
 
     def forward(self, x, z) -> torch.Tensor:
-        return super().forward(x, z)[0]
+        modulated, _ = AdaLayerNormZero.forward(self, x, z)
+        return modulated
