@@ -147,30 +147,35 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from nova_pointcloud_amd import hip
-    from nova_pointcloud_amd.sharding import gather_points
-    from diffnext.pipelines.nova.pipeline_nova import cosine_set_sizes, points_from_latents
+    from nova_pointcloud_amd.sharding import generate_sharded
+    from diffnext.pipelines.nova.pipeline_nova import cosine_set_sizes
 
     width, heads, H, W, B = WORKLOADS[args.workload]
     B = args.batch or B
     dtype = torch.float32 if dry else (torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     pipe = build_pipeline(width, heads, H, W, dtype, device)
-    prompts = synthetic_prompts(B, device, dtype, seed=1234 + rank)  # every rank generates its own shard
-    gen = torch.Generator(device=device).manual_seed(rank)
+    # the GLOBAL batch of prompts and ONE seed on every rank: each rank generates its contiguous block of samples and draws
+    # the order / noise tensors of the global batch (sharding.py: sharded(seed) == unsharded(seed))
+    prompts = synthetic_prompts(world * B, device, dtype, seed=1234)
+    gen = torch.Generator(device=device).manual_seed(0)
     sync = (lambda: None) if dry else torch.cuda.synchronize
     N, Nv = H * W, (H // 2) * (W // 2)
 
-    def step():
-        out = pipe(prompt_embeds=prompts, num_inference_steps=args.ar_steps, num_diffusion_steps=args.diffusion_steps,
-                   guidance_scale=5, generator=gen, output_type="latent", disable_progress_bar=True)
-        pts = points_from_latents(out.frames).float().contiguous()  # [B, N, 3]
-        # the path's only exchange: gather the generated point sets of all shards (RCCL over xGMI; no-op at N = 1)
-        return gather_points(pts)
+    def step(**extra):
+        # per-rank pipeline call on its shard + the path's only exchange: all_gather of the generated point sets
+        # (RCCL over xGMI; no collective at N = 1)
+        return generate_sharded(pipe, prompts, rank, world, num_inference_steps=args.ar_steps,
+                                num_diffusion_steps=args.diffusion_steps, guidance_scale=5, generator=gen, **extra)
 
     def fence():
         if world > 1:
             dist.barrier()
         sync()
 
+    if os.environ.get("NOVA_DUMP_MAPS"):  # diagnostics: attribute the frames of a native crash report to their libraries
+        import shutil
+
+        shutil.copyfile("/proc/self/maps", os.environ["NOVA_DUMP_MAPS"])
     for _ in range(args.warmup):
         pts = step()
     fence()
@@ -185,20 +190,14 @@ def main():
     # serialised, the brackets measure each kernel alone (and agree with rocprofv3 --kernel-trace, profiles/).
     prof, prof_elapsed = {}, 0.0
     if not dry:
-        lanes_env = os.environ.get("NOVA_LANES")
-        os.environ["NOVA_LANES"] = "1"
         hip.prof_enable(True)
         hip.prof_collect()
         t1 = time.perf_counter()
-        step()
+        step(lanes=1)
         fence()
         prof_elapsed = time.perf_counter() - t1
         prof = hip.prof_collect()
         hip.prof_enable(False)
-        if lanes_env is None:
-            del os.environ["NOVA_LANES"]
-        else:
-            os.environ["NOVA_LANES"] = lanes_env
     assert torch.isfinite(pts).all(), "non-finite points generated"
     assert pts.shape[0] == world * B, "gathered point sets do not cover the global batch"
     if world > 1:

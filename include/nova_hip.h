@@ -106,7 +106,7 @@ int nova_rope_table(const float* pos, const long long* ids, float* rope, int nb,
  * Element (s, l, head, c) of q lives at q + (s*Lq + l)*q_row_stride + head*head_dim + c (same
  * for k/v with Lk / kv_row_stride, o with o_row_stride); strides in elements, 16-byte multiples.
  * Replaces F.scaled_dot_product_attention at vision_transformer.py:63 and the
- * transpose(1,2).flatten(2) merge at :64. head_dim 64 is built. */
+ * transpose(1,2).flatten(2) merge at :64. head_dim 64 (d48w768, d48w1024) and 96 (d48w1536) are built. */
 int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int head_dim,
                   long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, void* stream);
 

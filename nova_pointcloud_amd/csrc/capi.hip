@@ -3,7 +3,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <cmath>
+#include <mutex>
 #include <utility>
 #include <vector>
 #include "common.h"
@@ -29,12 +31,14 @@ int check_launch(const char* what) {
 
 // ---- profiling: event pairs recorded around selected launches, summed on nova_prof_collect()
 struct ProfRec { hipEvent_t a, b; int slot; double work; };
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
+static std::mutex g_prof_mu;  // the record list is shared by all calling threads
 static std::vector<ProfRec> g_prof;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 
 ProfScope::ProfScope(int slot, double work, hipStream_t s) : idx(-1), st(s) {
-  if (!g_prof_on) return;
+  if (!g_prof_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   if (!g_prof_pool.empty()) {
     r.a = g_prof_pool.back().first;
@@ -50,7 +54,9 @@ ProfScope::ProfScope(int slot, double work, hipStream_t s) : idx(-1), st(s) {
   idx = (int)g_prof.size() - 1;
 }
 ProfScope::~ProfScope() {
-  if (idx >= 0) (void)hipEventRecord(g_prof[idx].b, st);
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (idx < (int)g_prof.size()) (void)hipEventRecord(g_prof[idx].b, st);
 }
 
 static inline bool bad_dtype(int dtype) { return dtype != NOVA_F32 && dtype != NOVA_BF16; }
@@ -71,11 +77,17 @@ using namespace nova;
   } while (0)
 
 namespace nova {
-static bool g_walk_rev = false;
+// Host-side launch state is per calling thread (ctypes releases the GIL during a call): the walk direction is set by a
+// composite for the launches it issues itself and restored when it returns, on every path.
+static thread_local bool g_walk_rev = false;
 void walk_reverse(bool on) { g_walk_rev = on; }
 bool walk_is_reverse() { return g_walk_rev; }
-static int g_walk_alternate = 1;  // experiments: nova_debug_force_gemm_tile(50000 / 50001) switches the alternation off / on
+#ifdef NOVA_EXPERIMENTS
+static int g_walk_alternate = 1;  // nova_debug_force_gemm_tile(50000 / 50001) switches the alternation off / on
 void walk_set_alternate(int on) { g_walk_alternate = on; }
+#else
+constexpr int g_walk_alternate = 1;
+#endif
 }  // namespace nova
 
 extern "C" {
@@ -94,19 +106,20 @@ int nova_check_device(void) {
 }
 
 int nova_debug_force_gemm_tile(int tile) {
-  NOVA_REQUIRE(tile == 0 || tile == 128 || tile == 256 || (tile >= 2560 && tile <= 2580) || (tile >= 7001 && tile <= 7064) || (tile >= 30000 && tile < 31000) || (tile >= 40000 && tile <= 40512) || tile == 50000 || tile == 50001, NOVA_ERR_ARG, "force_gemm_tile: 0, 128, 256 or 2560+variant");
-  gemm_force_tile(tile);
+  NOVA_REQUIRE(gemm_force_tile(tile) == 0, NOVA_ERR_ARG,
+               "force_gemm_tile: this build knows 0 (auto), 128 and 256 (experiment codes need the NOVA_EXPERIMENTS build)");
   return 0;
 }
 
 int nova_prof_enable(int on) {
-  g_prof_on = on != 0;
+  g_prof_on.store(on != 0);
   return 0;
 }
 
 int nova_prof_collect(double* ms, double* work, long long* launches, int slots) {
   NOVA_REQUIRE(ms && work && launches && slots >= PROF_SLOTS, NOVA_ERR_ARG, "prof_collect: need %d slots", PROF_SLOTS);
   for (int i = 0; i < slots; ++i) { ms[i] = 0; work[i] = 0; launches[i] = 0; }
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) {
     float t = 0.f;
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {

@@ -194,34 +194,42 @@ int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, i
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
                    hipStream_t st);
 
+// 0 = auto, 128 / 256 = force that tile structure (tests compare the two structures bit for bit). Thread-local like
+// the walk direction: a debugging knob of the calling host thread, not shared state.
+static thread_local int g_force_tile = 0;
+#ifdef NOVA_EXPERIMENTS
 void gemm256_set_variant(int v);
 void gemm256_set_gm(int g);
 void gemm256_set_stagger(int cycles);
 void gemm256_set_grid(int n);
 void walk_set_alternate(int on);
-static int g_force_tile = 0;  // 0 = auto, 128 / 256 = force (tests compare the two structures bit for bit)
-void gemm_force_tile(int tile) {
+#endif
+int gemm_force_tile(int tile) {
+#ifdef NOVA_EXPERIMENTS  // A/B knobs of tools/ (make exp): never compiled into the shipped library
   if (tile == 50000 || tile == 50001) {  // alternate the walk direction between launches of a block (off / on)
     walk_set_alternate(tile - 50000);
-    return;
+    return 0;
   }
   if (tile >= 40000 && tile <= 40512) {  // 40000 + n: persistent grid of n workgroups (0 = one per CU)
     gemm256_set_grid(tile - 40000);
-    return;
+    return 0;
   }
-  if (tile >= 30000 && tile < 31000) {  // 30000 + x: start stagger of the persistent 256 kernel, x * 256 cycles (experiments)
+  if (tile >= 30000 && tile < 31000) {  // 30000 + x: start stagger of the persistent 256 kernel, x * 256 cycles
     gemm256_set_stagger((tile - 30000) * 256);
-    return;
+    return 0;
   }
-  if (tile >= 7000 && tile < 7100) {  // 7000 + g: row panels per tile group of the 256 kernel (A/B experiments)
+  if (tile >= 7001 && tile <= 7064) {  // 7000 + g: row panels per tile group of the 256 kernel
     gemm256_set_gm(tile - 7000);
-    return;
+    return 0;
   }
-  if (tile >= 2560) {  // 2560 + v: force the 256 tile with schedule variant v (A/B experiments)
+  if (tile >= 2560 && tile <= 2580) {  // 2560 + v: force the 256 tile with schedule variant v (>= 10: timing-only, wrong results)
     gemm256_set_variant(tile - 2560);
     tile = 256;
   }
+#endif
+  if (tile != 0 && tile != 128 && tile != 256) return -1;
   g_force_tile = tile;
+  return 0;
 }
 
 template <typename T>

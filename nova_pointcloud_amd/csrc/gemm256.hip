@@ -81,6 +81,9 @@ __device__ __forceinline__ PFrag<T> punit_frag(const char* unit, int row, int ch
 // VAR selects where the two LDS-DMA instructions of a phase are issued (A/B-tested on the GPU, tools/microbench.py):
 //   0: both between the two k-halves of the MFMA segment   1: one in the load segment, one in the MFMA segment
 //   2: both in the load segment after the fragment reads   3: both in the load segment before the fragment reads
+// The shipped library instantiates VAR 2 only (the fallback of the persistent kernel). VAR 0/1/3 and the timing-only
+// ablations VAR 10-12 (no prefetch / no fragment reads / no barriers: WRONG results by design) exist only in the
+// -DNOVA_EXPERIMENTS build that tools/ loads (make -C nova_pointcloud_amd/csrc exp).
 template <typename T, int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                          T* __restrict__ C, int M, int N, int K, int ntm, int ntn,
@@ -619,12 +622,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   }
 }
 
+#ifdef NOVA_EXPERIMENTS
 static int g_gm256 = 8;
 static int g_stagger256 = 0;
 void gemm256_set_stagger(int cycles) { g_stagger256 = cycles; }
 void gemm256_set_gm(int g) { g_gm256 = g; }
 static int g_var256 = 20;  // measured best (tools/gemm_variants.py): the persistent form; 0-3 = one tile per workgroup, LDS-DMA placement variants
 void gemm256_set_variant(int v) { g_var256 = v; }
+#else
+constexpr int g_gm256 = 8;       // row panels per tile group
+constexpr int g_stagger256 = 0;  // no start stagger
+constexpr int g_var256 = 20;     // the persistent form
+#endif
 
 template <typename T, int VAR>
 static int launch256v(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
@@ -645,8 +654,12 @@ static int launch256v(const void* A, const void* W, void* C, int M, int N, int K
   return check_launch("gemm256");
 }
 
+#ifdef NOVA_EXPERIMENTS
 static int g_grid256 = 0;  // 0 = one workgroup per CU; otherwise the persistent grid size (a multiple of 8)
 void gemm256_set_grid(int n) { g_grid256 = n & ~7; }
+#else
+constexpr int g_grid256 = 0;
+#endif
 static int cu_slots() {  // persistent grid: one workgroup per CU, a multiple of the 8 XCDs
   if (g_grid256 > 0) return g_grid256;
   static int n = 0;
@@ -704,6 +717,7 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
                      hipStream_t st) {
   // (the persistent RoPE epilogue steps through a 16-row block assuming it crosses at most one sequence boundary)
   if (g_var256 == 20 && !(epi == E_ROPE && e.rope && e.L < 16)) return launch256p<T>(A, W, C, M, N, K, epi, e, st);
+#ifdef NOVA_EXPERIMENTS
   switch (g_var256) {
     case 1: return launch256v<T, 1>(A, W, C, M, N, K, epi, e, st);
     case 3: return launch256v<T, 3>(A, W, C, M, N, K, epi, e, st);
@@ -711,8 +725,10 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
     case 10: return launch256v<T, 10>(A, W, C, M, N, K, epi, e, st);
     case 11: return launch256v<T, 11>(A, W, C, M, N, K, epi, e, st);
     case 12: return launch256v<T, 12>(A, W, C, M, N, K, epi, e, st);
-    default: return launch256v<T, 2>(A, W, C, M, N, K, epi, e, st);
+    default: break;
   }
+#endif
+  return launch256v<T, 2>(A, W, C, M, N, K, epi, e, st);
 }
 
 // Entry used by gemm.hip's dispatcher. Preconditions (checked by the caller): N % 256 == 0,

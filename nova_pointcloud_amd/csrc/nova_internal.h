@@ -29,7 +29,7 @@ int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const floa
 
 int gemm_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
                    int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st);
-void gemm_force_tile(int tile);
+int gemm_force_tile(int tile);  // 0 on success, -1 for a value this build does not know
 // traversal direction of the NEXT launches of the row-tiled kernels (persistent GEMM, attention, row_norm); see
 // xcd_remap_dir in common.h. Set by the block composites, false for direct calls of the single-kernel entry points.
 void walk_reverse(bool on);

@@ -77,6 +77,7 @@ class MaskEmbed(nn.Module):
         self.generator = None
         self.pred_ids = None
         self.pred_pos = 0
+        self.batch_shard = None  # (lo, hi, total): this process generates rows [lo, hi) of a batch of `total` (sharding.py)
 
     # ---- generation state ---------------------------------------------------------------
     def apply_mask(self, x) -> torch.Tensor:
@@ -84,7 +85,11 @@ class MaskEmbed(nn.Module):
 
     def get_pred_mask(self, num_preds) -> Tuple[torch.Tensor, torch.Tensor]:
         if self.pred_ids is None:
-            draw = torch.empty_like(self.mask).uniform_(generator=self.generator)
+            if self.batch_shard is None:
+                draw = torch.empty_like(self.mask).uniform_(generator=self.generator)
+            else:  # sharded batch: draw for the global batch, keep this shard's rows (same order as the unsharded run)
+                lo, hi, total = self.batch_shard
+                draw = self.mask.new_empty((total,) + tuple(self.mask.shape[1:])).uniform_(generator=self.generator)[lo:hi]
             self.pred_ids = draw.argsort(dim=1)
         chosen = self.pred_ids[:, self.pred_pos : self.pred_pos + num_preds]
         self.pred_pos += num_preds

@@ -135,6 +135,9 @@ class Transformer3DModel(nn.Module):
         """Masked set-by-set generation of one frame (for point sets: the whole sample)."""
         scaler = GuidanceScaler(**inputs)
         generator = self.mask_embed.generator = inputs.get("generator", None)
+        shard = self.mask_embed.batch_shard = inputs.get("batch_shard", None)
+        if shard is not None and type(self.sample_scheduler).__name__ == "DDPMScheduler":
+            raise NotImplementedError("batch_shard with the ancestral sampler is built on the HIP path only")
         schedule = [n for n in inputs["num_preds"] if n > 0]
         pe = self.image_encoder.patch_embed
         c, x, self.mask_embed.mask = states["c"], states["x"].zero_(), None
@@ -149,7 +152,11 @@ class Transformer3DModel(nn.Module):
                 prev_ids = pred_ids.new_empty((pred_ids.size(0), 0, 1))
             z = self.image_encoder(scaler.expand(z), c, prev_ids, pos=pos)
             prev_ids = torch.cat([prev_ids, pred_ids], dim=1)
-            states["noise"].normal_(generator=generator)
+            if shard is None:
+                states["noise"].normal_(generator=generator)
+            else:  # global-batch draw, this shard's rows (sharded(seed) == unsharded(seed))
+                full = states["noise"].new_empty((shard[2],) + tuple(states["noise"].shape[1:])).normal_(generator=generator)
+                states["noise"].copy_(full[shard[0]:shard[1]])
             sample = self.denoise(z, states["noise"], scaler.clone(), generator, pred_ids)
             x.add_(pe.unpatchify(sample * pred_mask))
 

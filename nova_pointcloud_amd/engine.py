@@ -20,14 +20,16 @@ Data layout in HBM (all row-major, one token per row):
 """
 import ctypes
 
-import numpy as np
 import os
 
+import numpy as np
 import torch
 
 from . import hip
 
 _F32 = torch.float32
+# default number of half-batch lanes; read ONCE at import (an experiment knob of tools/lanes_ab.py, 0 = the rule below)
+_ENV_LANES = int(os.environ.get("NOVA_LANES", "0") or 0)
 
 
 def _f32(t):
@@ -333,39 +335,40 @@ class NovaEngine(object):
         if latents:  # prefilled first frame with max_latent_length == 1: nothing to generate (transformer_3d.py:159-160)
             return torch.stack([latents[-1].to(device=dev, dtype=dtype)], dim=2)
 
-        # ---- random draws for the WHOLE batch, in the reference's order (embeddings.py:265; transformer_3d.py:131)
+        # ---- random draws for the WHOLE batch, in the reference's order (embeddings.py:265; transformer_3d.py:131).
+        # Batch-sharded runs (sharding.py) pass batch_shard = (lo, hi, total): every rank then draws the
+        # tensors of the GLOBAL batch from the same seed and keeps its rows, so sharded(seed) == unsharded(seed).
+        g_lo, g_hi, g_B = inputs.get("batch_shard", None) or (0, B, B)
+        if g_hi - g_lo != B or not (0 <= g_lo <= g_hi <= g_B):
+            raise ValueError(f"batch_shard {(g_lo, g_hi, g_B)} does not describe this call's {B} samples")
         order = inputs.get("pred_order", None)  # test hook: inject the generation order [B, N]
         if order is None:
-            u = torch.empty(B, N, 1, dtype=_F32, device=rng_dev).uniform_(generator=generator)
-            order = u.argsort(dim=1)[..., 0]
+            u = torch.empty(g_B, N, 1, dtype=_F32, device=rng_dev).uniform_(generator=generator)
+            order = u[g_lo:g_hi].argsort(dim=1)[..., 0]
         order = order.to(dev).contiguous()
         m.mask_embed.pred_ids = order.unsqueeze(-1)
         noise_fn = inputs.get("noise_fn", None)  # test hook: replay recorded per-step noise
-        noise_buf = torch.empty(B, C, H, W, dtype=_F32, device=rng_dev)
+        noise_buf = torch.empty(g_B, C, H, W, dtype=_F32, device=rng_dev)
 
         def draw(i, n):
             """Per-AR-step draws: x_T canvas [B,N,P] and, for an ancestral sampler, one gaussian canvas per step with t > 0."""
             if noise_fn is not None:
                 nz = noise_fn(i).to(_F32)
             else:
-                nz = noise_buf.normal_(generator=generator)
+                nz = noise_buf.normal_(generator=generator)[g_lo:g_hi]
             nz = nz.to(dev).reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P)
             extra = None
             if ancestral:  # scheduling_ddpm.py:303-305
-                extra = [torch.randn(B, C, H, W, generator=generator, device=rng_dev, dtype=_F32).to(dev)
+                extra = [torch.randn(g_B, C, H, W, generator=generator, device=rng_dev, dtype=_F32)[g_lo:g_hi].to(dev)
                          .reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P) if coefs[j][5] != 0.0 else None
                          for j in range(steps)]
             return nz, extra
 
         # measured (MI355X): two lanes +6 % at batch 8 (d48w768 / 1024 points) and +3 % at batch 32 (d48w1024 / 2048 points)
         # once the encoder GEMMs are persistent (one lane's row kernels, decoder launches and epilogue store bursts fill
-        # the other's memory-idle K loops); four lanes lose 10 % (quarter-size GEMMs). NOVA_LANES overrides for experiments.
-        lanes = int(inputs.get("lanes", 0)) or int(os.environ.get("NOVA_LANES", 0)) or (2 if B >= 4 else 1)
+        # the other's memory-idle K loops); four lanes lose 10 % (quarter-size GEMMs).
+        lanes = int(inputs.get("lanes", 0)) or _ENV_LANES or (2 if B >= 4 else 1)
         lanes = max(1, min(lanes, B))
-        if "NOVA_WALK_ALT" in os.environ:  # experiments: alternate the tile-walk direction between launches (1) or not (0)
-            hip.call("nova_debug_force_gemm_tile", 50000 + int(os.environ["NOVA_WALK_ALT"]))
-        if "NOVA_GEMM_GRID" in os.environ:  # experiments: persistent encoder-GEMM grid (workgroups), 0 = one per CU
-            hip.call("nova_debug_force_gemm_tile", 40000 + int(os.environ["NOVA_GEMM_GRID"]))
         main = torch.cuda.current_stream()
         bounds = [(B * k // lanes, B * (k + 1) // lanes) for k in range(lanes)]
         prompt = prompt.to(device=dev, dtype=dtype)

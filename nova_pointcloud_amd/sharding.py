@@ -3,8 +3,11 @@
 Samples are independent (no cross-sample op anywhere in the path), so the path shards by batch row:
 rank r generates a contiguous block of the prompts with replicated weights, and the only exchange
 is one all-gather of the generated point sets ([B_loc, N, 3] f32 per rank) — RCCL over xGMI on
-GPUs (`backend="nccl"`), gloo in the CPU tests. Each rank's call is an ordinary pipeline call, so
-per-shard parity with the reference is the single-process parity.
+GPUs (`backend="nccl"`), gloo in the CPU tests.
+
+Seed contract: every rank seeds its generator identically and passes `batch_shard=(lo, hi, total)`; the generation
+order uniforms (embeddings.py:265) and the per-step noise (transformer_3d.py:131) are then drawn for the GLOBAL batch
+and sliced, so `sharded(seed) == unsharded(seed)` sample for sample (`generate_sharded`).
 """
 import torch
 
@@ -45,3 +48,16 @@ def gather_points(points, group=None):
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([p[:n] for p, n in zip(parts, counts)])
+
+
+def generate_sharded(pipe, prompt_embeds, rank, world, group=None, **call_kwargs):
+    """Run `pipe` on this rank's contiguous block of `prompt_embeds` (the GLOBAL list) and return the point sets of
+    the whole batch [len(prompt_embeds), N, 3] on every rank. `call_kwargs` are `NOVAPipeline.__call__` arguments; a
+    `generator` must be seeded identically on all ranks (its draws cover the global batch)."""
+    from diffnext.pipelines.nova.pipeline_nova import points_from_latents
+
+    per = int(call_kwargs.get("num_images_per_prompt", 1))
+    lo, hi = shard_range(len(prompt_embeds), rank, world)
+    out = pipe(prompt_embeds=list(prompt_embeds[lo:hi]), output_type="latent", disable_progress_bar=True,
+               batch_shard=(lo * per, hi * per, len(prompt_embeds) * per), **call_kwargs)
+    return gather_points(points_from_latents(out.frames).float().contiguous(), group)

@@ -1,0 +1,110 @@
+"""End-to-end parity of the HIP generation path with the oracle at the BASELINE architectures.
+
+The golden fixtures (tests/golden) pin the oracle on 2-block, D=128 models. What they cannot show is
+error growth through the real depth: 16 conditioning blocks + 32 masked-AR blocks + 6 diffusion blocks
+at D = 768 / 1024 / 1536. Here `NOVAPipeline` runs the real NOVA-d48 architectures (random-init under
+`torch.manual_seed(0)`, the bench's weights) on the GPU and `oracle.generate` runs the same weights,
+prompts and host generator on the CPU, at reduced AR / diffusion step counts so the oracle finishes in
+seconds (SURVEY §8d parity chain (ii)/(iii); BASELINE.json configs[1], [2], [4]).
+
+  f32 mode   (exact-f32 MFMA): max|d| / max|x| <= 1e-3 on the point coordinates (north_star).
+  bf16 mode  (throughput mode): generation order and noise injected (the reference draws them in the
+             activation dtype, so a bf16 seed is not comparable), rms-relative error reported and
+             bounded; the reference's own CPU-bf16 level on the toy model is ~2e-2.
+Measured errors are printed (`pytest -s`) and recorded in DESIGN.md §2.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import nova_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "nova_pointcloud_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def rms_rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+
+
+# (width, heads, latent H, W, batch, AR steps, diffusion steps, bf16 rms-rel bound)
+ARCHS = {
+    "d48w1024_2048pts": (1024, 16, 32, 64, 2, 3, 2, 6e-2),  # configs[2] / [3]: the headline architecture
+    "d48w768_1024pts": (768, 12, 32, 32, 2, 3, 2, 6e-2),    # configs[1]
+    "d48w1536_2048pts": (1536, 16, 32, 64, 1, 2, 2, 6e-2),  # configs[4] architecture (head_dim 96) in f32 / bf16
+}
+
+
+@pytest.fixture(scope="module", params=sorted(ARCHS))
+def case(request):
+    """Builds the architecture once (CPU f32 master copy), runs the oracle once, and hands both to the tests."""
+    import bench
+
+    width, heads, H, W, B, K, S, bf16_bound = ARCHS[request.param]
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(threads, bench.host_cores()))
+    pipe = bench.build_pipeline(width, heads, H, W, torch.float32, torch.device("cpu"))
+    sd = {k: v.detach().clone() for k, v in pipe.transformer.state_dict().items()}
+    prompts = bench.synthetic_prompts(B, "cpu", torch.float32, seed=4321)
+    N = H * W
+    # the draws a host generator seeded with 29 yields in the path's order (embeddings.py:265, transformer_3d.py:131): one
+    # uniform [B,N,1], then one normal [B,C,H,W] per AR step. Injecting them must reproduce the seeded run, so ONE oracle
+    # run serves the seeded f32 test and the injected bf16 test.
+    g = torch.Generator().manual_seed(29)
+    u_dist = torch.empty(B, N, 1).uniform_(generator=g)
+    sched = [int(v) for v in O.cosine_schedule(N, K) if v > 0]
+    noises = [torch.empty(B, 3, H, W).normal_(generator=g) for _ in sched]
+    cfg = O.make_config(3, (H, W), 1, width, heads, 16, 32, 6, 256, rotary=True)
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 256)
+    with torch.no_grad():
+        ref = O.generate(sd, cfg, prompt, sched, num_diffusion_steps=S, guidance_scale=5.0, generator=torch.Generator().manual_seed(29))
+    torch.set_num_threads(threads)
+    return dict(name=request.param, pipe=pipe, prompts=prompts, K=K, S=S, order=u_dist.argsort(dim=1)[..., 0], noises=noises,
+                ref=ref, bf16_bound=bf16_bound, shape=(B, 3, 1, H, W))
+
+
+def run(case, dtype, **kw):
+    """One pipeline call on a GPU copy of the model in `dtype` (the CPU f32 master copy stays untouched)."""
+    import copy
+
+    from diffnext.pipelines import NOVAPipeline
+    from diffnext.schedulers import FlowMatchEulerDiscreteScheduler
+
+    model = copy.deepcopy(case["pipe"].transformer).to(device="cuda", dtype=dtype).eval()
+    pipe = NOVAPipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler(num_train_timesteps=1000, shift=1.0))
+    out = pipe(prompt_embeds=[p.to("cuda", dtype) for p in case["prompts"]], num_inference_steps=case["K"],
+               num_diffusion_steps=case["S"], guidance_scale=5, output_type="latent", disable_progress_bar=True, **kw).frames
+    torch.cuda.synchronize()
+    return out.float().cpu()
+
+
+def test_f32_from_seed_matches_oracle_at_full_depth(case, hip):
+    """Same prompts + same host generator seed: HIP f32 path vs the oracle, 1e-3 relative on the coordinates."""
+    x = run(case, torch.float32, generator=torch.Generator().manual_seed(29))
+    assert tuple(x.shape) == case["shape"] and torch.isfinite(x).all()
+    err, rms = rel(x, case["ref"]), rms_rel(x, case["ref"])
+    print(f"\n[parity-full] {case['name']} f32 from seed: max rel {err:.3e}, rms rel {rms:.3e}")
+    assert err < 1e-3, err
+
+
+def test_bf16_injected_draws_close_to_oracle_at_full_depth(case, hip):
+    """Throughput mode (bf16 storage, f32 accumulate): weights rounded to bf16 on the GPU side only - the error
+    reported is the whole bf16 effect against the f32 reference, as north_star's 'bf16 vs reference CPU path'."""
+    order, noises = case["order"], case["noises"]
+    x = run(case, torch.bfloat16, pred_order=order, noise_fn=lambda i: noises[i])
+    assert torch.isfinite(x).all()
+    err, mx = rms_rel(x, case["ref"]), rel(x, case["ref"])
+    print(f"\n[parity-full] {case['name']} bf16 injected: rms rel {err:.3e}, max rel {mx:.3e}")
+    assert err < case["bf16_bound"], err

@@ -16,8 +16,6 @@ for path in sys.argv[1:]:
         if hasattr(lib, name):
             getattr(lib, name).argtypes, getattr(lib, name).restype = argtypes, ctypes.c_int
     libs[os.path.basename(path)] = lib
-    if "_pp" in os.path.basename(path):
-        lib.nova_debug_force_gemm_tile(9001)
 dt = torch.bfloat16
 st = torch.cuda.current_stream().cuda_stream
 g = torch.Generator().manual_seed(0)

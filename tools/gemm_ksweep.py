@@ -6,7 +6,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nova_pointcloud_amd import hip  # noqa: E402
-from microbench import timeit  # noqa: E402
+from microbench import timeit, use_experiments_lib  # noqa: E402
+
+use_experiments_lib()
 
 dt = torch.bfloat16
 M = 64 * 2560

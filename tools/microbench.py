@@ -9,6 +9,15 @@ sys.path.insert(0, ROOT)
 from nova_pointcloud_amd import hip  # noqa: E402
 
 
+def use_experiments_lib():
+    """Point the binding at libnova_hip_exp.so (`make -C nova_pointcloud_amd/csrc exp`): the -DNOVA_EXPERIMENTS build
+    with the A/B schedule variants and the timing-only ablation kernels. Call before the first hip.load()."""
+    path = os.path.join(ROOT, "nova_pointcloud_amd", "libnova_hip_exp.so")
+    if not os.path.exists(path):
+        raise SystemExit(f"{path} not found: run `make -C nova_pointcloud_amd/csrc exp` first")
+    hip._LIB_PATH = path
+
+
 def timeit(fn, iters=10, warm=3):
     for _ in range(warm):
         fn()
