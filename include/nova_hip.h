@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NOVA_HIP_VERSION 100 /* 0.1.0 */
+#define NOVA_HIP_VERSION 200 /* 0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows */
 
 typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1 } nova_dtype;
 typedef enum { NOVA_ACT_NONE = 0, NOVA_ACT_GELU_ERF = 1, NOVA_ACT_SILU = 2 } nova_act;
@@ -175,6 +175,20 @@ int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, 
                             int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
                             void* ws_h, int dtype, void* stream);
 
+/* The same block stack for the conditioning encoder of multi-frame generation (max_latent_length > 1): the k | v rows
+ * each block's fused QKV projection produces for the L rows of x are appended to that block's cache and attention runs
+ * over cache_len + L keys (vision_transformer.py:55-60: `torch.cat([cache_kv, k], dim=2)`; enable_kvcache :125-126).
+ *   kv_cache [nblocks][S][cache_cap][2D] in `dtype` (k then v per row, k already rotated), caller-owned; rows
+ *   [0, cache_len) of every sequence are valid on entry, [cache_len, cache_len + L) on return. The caller advances
+ *   cache_len by L after the call. rope covers the L new rows only ([rope_batch, L, hd/2, 2]). */
+int nova_vit_blocks_forward_kv(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
+                               int hidden, const float* rope, int rope_batch, void* kv_cache, long cache_cap,
+                               long cache_len, void* ws_qkv, void* ws_a, void* ws_b, void* ws_h, int dtype, void* stream);
+
+/* out[r, :] = x[r, :] * (1 + mod[r, 0:D]) + mod[r, D:2D]: AdaLayerNorm with eps=None (no normalisation), the frame mixer
+ * `video_encoder.mixer` of transformer_nova.py:87-89 / normalization.py:39-46 applied at transformer_3d.py:156-158. */
+int nova_modulate_rows(const void* x, const void* mod, void* out, long rows, int D, int dtype, void* stream);
+
 typedef struct {
   const void* fc1_w;  /* blocks.i.proj.fc1.weight [D, D] */
   const float* fc1_b;
@@ -200,9 +214,14 @@ typedef struct {
  * Flow-matching Euler (scheduling_cfm.py:134-136): kx=0, kv=1, clip=0, c0=sigma_{i+1}-sigma_i, cx=1, sigma=0.
  * DDPM (scheduling_ddpm.py:236-316): kx, kv from prediction_type (:271-280), clip = clip_sample_range (:283-289),
  * c0 / cx the posterior-mean coefficients (:293-298), sigma the posterior std (:303-312).
- * guidance <= 1 disables CFG for that step (guidance_trunc, guidance_scaler.py:59-65). */
+ * guidance <= 1 disables CFG for that step (guidance_trunc, guidance_scaler.py:59-65).
+ * 3-pass guidance (guidance_scaler.py:46-57,78-85; rows [cond ; uncond ; third], S = 3B): extra_kind 1 = image guidance
+ * (third = uncond text with the image condition): v = u + g (c - t) [renorm] + extra_scale (t - u); extra_kind 2 =
+ * spatiotemporal guidance (third = cond text): v = u + g (c - u) [renorm] + extra_scale (c - t); 0 = 2-pass. */
 typedef struct {
   float guidance, kx, kv, clip, c0, cx, sigma;
+  float extra_scale;
+  int extra_kind;
 } nova_sampler_step;
 
 /* All `steps` sampler steps of Transformer3DModel.denoise (transformer_3d.py:102-113) for the n tokens predicted in
@@ -214,8 +233,9 @@ typedef struct {
  *   noise [steps, B, n, P] f32 or NULL: the per-step gaussian rows of an ancestral sampler (used where sigma != 0)
  *   renorm           guidance_renorm (>= 1: off). When < 1 (flow-matching Euler only): guidance_scaler.py:67-72 with
  *                    echo_energy [B] f32 in/out = squared norm of each sample's rows that are NOT predicted in this AR
- *                    step (they echo x_t in the reference and enter both norms), ws_v [2*B*n*P] f32 scratch.
- * S = 2B when any sched[i].guidance > 1 (cond rows then uncond rows), else S = B.
+ *                    step (they echo x_t in the reference and enter both norms), ws_v [2*B*n*P] f32 scratch
+ *                    ([3*B*n*P] with 3-pass guidance).
+ * S = 2B when any sched[i].guidance > 1 (cond rows then uncond rows; 3B with a third guidance pass), else S = B.
  * Workspaces in `dtype`: ws_a, ws_u, ws_h, ws_f, ws_g [S*n, D]; ws_mod [S*n, (3*depth+2)*D]. */
 int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
                          const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,

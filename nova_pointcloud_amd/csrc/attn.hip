@@ -39,7 +39,7 @@ template <int HD>
 __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                     const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                                     int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
-                                                                    int heads, int nq, int rev) {
+                                                                    int heads, int nq, int rev, long kv_ss) {
   constexpr int NKS = HD / 16, NDV = HD / 32;
   constexpr int BUF = 2 * A_T64 + (HD == 96 ? 2 * A_T32 : 0);  // [K64 | V64 | K32 | V32]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
   const int q0 = qt * 128 + wid * 32;
 
   const bf16_t* qb = q + (size_t)s * Lq * q_rs + head * HD;
-  const bf16_t* kb_ = k + (size_t)s * Lk * kv_rs + head * HD;
-  const bf16_t* vb_ = v + (size_t)s * Lk * kv_rs + head * HD;
+  const bf16_t* kb_ = k + (size_t)s * kv_ss + head * HD;
+  const bf16_t* vb_ = v + (size_t)s * kv_ss + head * HD;
 
   // Q fragments: B operand of S^T = K Q^T; lane (r, hh) holds Q[q0 + r][16 ks + 8 hh + 0..7]
   bf8v qf[NKS];
@@ -258,7 +258,7 @@ constexpr int F_KV = 32;
 template <int HD>
 __global__ __launch_bounds__(256) void attn_f32(const float* __restrict__ q, const float* __restrict__ k,
                                                 const float* __restrict__ v, float* __restrict__ o, int Lq, int Lk,
-                                                long q_rs, long kv_rs, long o_rs, float c) {
+                                                long q_rs, long kv_rs, long o_rs, float c, long kv_ss) {
   constexpr int ROWB = HD * 4, TILE = F_KV * ROWB, NCS = HD / 8, NDV = HD / 32, PPW = TILE / 4096;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(256) void attn_f32(const float* __restrict__ q, con
   const int q0 = blockIdx.x * 128 + wid * 32;
 
   const float* qb = q + (size_t)s * Lq * q_rs + head * HD;
-  const float* kb_ = k + (size_t)s * Lk * kv_rs + head * HD;
-  const float* vb_ = v + (size_t)s * Lk * kv_rs + head * HD;
+  const float* kb_ = k + (size_t)s * kv_ss + head * HD;
+  const float* vb_ = v + (size_t)s * kv_ss + head * HD;
 
   // lane (r, hh) holds Q[q0 + r][4 (2 cs + hh) + j]; MFMA step (cs, j) contracts the k pair
   // {4(2cs)+j, 4(2cs+1)+j} (any consistent order is a valid contraction)
@@ -378,12 +378,14 @@ __global__ __launch_bounds__(256) void attn_f32(const float* __restrict__ q, con
 }
 
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
-             long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st, bool q_prescaled) {
+             long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st, bool q_prescaled, long kv_ss) {
   if (S <= 0 || Lq <= 0) return 0;
   if (hd != 64 && hd != 96) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64 and 96)", hd);
   if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
   const int align = dtype == NOVA_BF16 ? 8 : 4;  // 16-byte row alignment for the vector loads
   if (q_rs % align || kv_rs % align || o_rs % align) return set_error(NOVA_ERR_SHAPE, "attn_fwd: row strides must be 16-byte multiples");
+  if (kv_ss == 0) kv_ss = (long)Lk * kv_rs;
+  if (kv_ss % align || kv_ss < (long)Lk * kv_rs) return set_error(NOVA_ERR_SHAPE, "attn_fwd: kv sequence stride must cover Lk rows and be a 16-byte multiple");
   const int nq = (Lq + 127) / 128;
   if (S > 65535 || heads > 65535 || (long)nq * heads * S > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
   const float c = scale * 1.4426950408889634f;
@@ -393,12 +395,12 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
     const float cl = q_prescaled ? 1.0f : c;
     const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v;
     const int rev = walk_is_reverse() ? 1 : 0;
-    if (hd == 64) hipLaunchKernelGGL(attn_bf16<64>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev);
-    else hipLaunchKernelGGL(attn_bf16<96>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev);
+    if (hd == 64) hipLaunchKernelGGL(attn_bf16<64>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss);
+    else hipLaunchKernelGGL(attn_bf16<96>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss);
   } else {
     const float *qq = (const float*)q, *kk = (const float*)k, *vv = (const float*)v;
-    if (hd == 64) hipLaunchKernelGGL(attn_f32<64>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);
-    else hipLaunchKernelGGL(attn_f32<96>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c);
+    if (hd == 64) hipLaunchKernelGGL(attn_f32<64>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c, kv_ss);
+    else hipLaunchKernelGGL(attn_f32<96>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c, kv_ss);
   }
   return check_launch("attn_fwd");
 }

@@ -238,18 +238,17 @@ int nova_head_cfg_euler(const void* h, const void* w, const float* bias, float* 
   NOVA_REQUIRE(h && w && bias && x, NOVA_ERR_ARG, "head_cfg_euler: null pointer");
   // the kernel takes "guidance > 1" as the CFG switch; cfg != 0 with g <= 1 still combines (u + g (c - u))
   NOVA_REQUIRE(!cfg || guidance > 1.0f, NOVA_ERR_ARG, "head_cfg_euler: cfg needs guidance > 1");
-  SamplerStep sp{cfg ? guidance : 1.0f, 0.f, 1.f, 0.f, dt, 1.f, 0.f};
-  return head_cfg_step(h, w, bias, x, nullptr, nullptr, nullptr, B, n, P, D, sp, 0, dtype, (hipStream_t)stream);
+  SamplerStep sp{cfg ? guidance : 1.0f, 0.f, 1.f, 0.f, dt, 1.f, 0.f, 0.f, 0};
+  return head_cfg_step(h, w, bias, x, nullptr, nullptr, nullptr, nullptr, B, n, P, D, sp, 0, dtype, (hipStream_t)stream);
 }
 
 
-int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
-                            int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
-                            void* ws_h, int dtype, void* stream) {
-  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "vit_blocks: bad dtype %d", dtype);
-  NOVA_REQUIRE(nblocks == 0 || (blocks && x && ws_qkv && ws_a && ws_b && ws_h), NOVA_ERR_ARG, "vit_blocks: null pointer");
-  NOVA_REQUIRE(heads > 0 && D % heads == 0, NOVA_ERR_SHAPE, "vit_blocks: D %% heads != 0");
-  hipStream_t st = (hipStream_t)stream;
+// Block stack of VisionTransformer.forward. With `cache` the k | v rows of every block are appended to that block's
+// cache ([S][cap][2D], `cache_len` rows already valid) and attention runs over cache_len + L keys
+// (vision_transformer.py:55-60, the conditioning encoder of multi-frame generation); without it over the L rows of x.
+static int vit_blocks(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads, int hidden,
+                      const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b, void* ws_h, void* cache,
+                      long cap, long cache_len, int dtype, hipStream_t st) {
   const int M = S * L, hd = D / heads;
   if (M == 0) return 0;
   const size_t es = esize(dtype);
@@ -269,8 +268,15 @@ int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, 
     NOVA_TRY(gemm_qkv_rope(x, b.qkv_w, b.qkv_b, rope, ws_qkv, S, L, D, heads, rope_batch, dtype, st,
                            pre ? scale * 1.4426950408889634f : 1.0f));
     walk.next();
-    NOVA_TRY(attn_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, ws_a, S, heads, L, L, hd, 3L * D, 3L * D, D,
-                      scale, dtype, st, pre));
+    if (cache) {
+      char* cb = static_cast<char*>(cache) + (size_t)i * S * cap * 2 * D * es;
+      NOVA_TRY(kv_append(ws_qkv, cb, S, L, D, cap, cache_len, dtype, st));
+      NOVA_TRY(attn_fwd(qkv, cb, cb + (size_t)D * es, ws_a, S, heads, L, (int)(cache_len + L), hd, 3L * D, 2L * D, D, scale, dtype,
+                        st, pre, cap * 2L * D));
+    } else {
+      NOVA_TRY(attn_fwd(qkv, qkv + (size_t)D * es, qkv + (size_t)2 * D * es, ws_a, S, heads, L, L, hd, 3L * D, 3L * D, D,
+                        scale, dtype, st, pre));
+    }
     walk.next();
     NOVA_TRY(gemm_bias_act(ws_a, b.proj_w, b.proj_b, ws_b, M, D, D, NOVA_ACT_NONE, dtype, st));
     RowNormArgs n1{ws_b, x, b.norm1_w, b.norm1_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
@@ -287,6 +293,34 @@ int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, 
   return 0;
 }
 
+int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
+                            int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
+                            void* ws_h, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "vit_blocks: bad dtype %d", dtype);
+  NOVA_REQUIRE(nblocks == 0 || (blocks && x && ws_qkv && ws_a && ws_b && ws_h), NOVA_ERR_ARG, "vit_blocks: null pointer");
+  NOVA_REQUIRE(heads > 0 && D % heads == 0, NOVA_ERR_SHAPE, "vit_blocks: D %% heads != 0");
+  return vit_blocks(blocks, nblocks, x, S, L, D, heads, hidden, rope, rope_batch, ws_qkv, ws_a, ws_b, ws_h, nullptr, 0, 0, dtype,
+                    (hipStream_t)stream);
+}
+
+int nova_vit_blocks_forward_kv(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
+                               int hidden, const float* rope, int rope_batch, void* kv_cache, long cache_cap,
+                               long cache_len, void* ws_qkv, void* ws_a, void* ws_b, void* ws_h, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "vit_blocks_kv: bad dtype %d", dtype);
+  NOVA_REQUIRE(nblocks == 0 || (blocks && x && kv_cache && ws_qkv && ws_a && ws_b && ws_h), NOVA_ERR_ARG, "vit_blocks_kv: null pointer");
+  NOVA_REQUIRE(heads > 0 && D % heads == 0, NOVA_ERR_SHAPE, "vit_blocks_kv: D %% heads != 0");
+  NOVA_REQUIRE(cache_len >= 0 && cache_len + L <= cache_cap, NOVA_ERR_SHAPE, "vit_blocks_kv: %ld cached + %d new rows exceed the capacity %ld",
+               cache_len, L, cache_cap);
+  return vit_blocks(blocks, nblocks, x, S, L, D, heads, hidden, rope, rope_batch, ws_qkv, ws_a, ws_b, ws_h, kv_cache, cache_cap,
+                    cache_len, dtype, (hipStream_t)stream);
+}
+
+int nova_modulate_rows(const void* x, const void* mod, void* out, long rows, int D, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "modulate_rows: bad dtype %d", dtype);
+  NOVA_REQUIRE(rows == 0 || (x && mod && out), NOVA_ERR_ARG, "modulate_rows: null pointer");
+  return modulate_rows(x, mod, out, rows, D, dtype, (hipStream_t)stream);
+}
+
 int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
                          const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
                          void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int dtype,
@@ -294,7 +328,7 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
   NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "decoder_denoise: bad dtype %d", dtype);
   NOVA_REQUIRE(dec && zc && temb && x && sched && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
                "decoder_denoise: null pointer");
-  NOVA_REQUIRE(S == B || S == 2 * B, NOVA_ERR_SHAPE, "decoder_denoise: S must be B or 2B");
+  NOVA_REQUIRE(S == B || S == 2 * B || S == 3 * B, NOVA_ERR_SHAPE, "decoder_denoise: S must be B, 2B or 3B");
   const bool do_renorm = renorm < 1.0f;
   NOVA_REQUIRE(!do_renorm || (echo_energy && ws_v), NOVA_ERR_ARG, "decoder_denoise: renorm needs echo_energy and ws_v");
   if (n == 0 || B == 0) return 0;
@@ -302,13 +336,17 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
   const size_t es = esize(dtype);
   const int depth = dec->depth;
   const long mod_ld = (long)(3 * depth + 2) * D;
+  const size_t nP = (size_t)B * n * P;
   for (int i = 0; i < steps; ++i) {
-    const SamplerStep sp{sched[i].guidance, sched[i].kx, sched[i].kv, sched[i].clip, sched[i].c0, sched[i].cx, sched[i].sigma};
+    const SamplerStep sp{sched[i].guidance, sched[i].kx,    sched[i].kv,          sched[i].clip,      sched[i].c0,
+                         sched[i].cx,       sched[i].sigma, sched[i].extra_scale, sched[i].extra_kind};
     const int cfg = sp.guidance > 1.0f ? 1 : 0;
-    NOVA_REQUIRE(!cfg || S == 2 * B, NOVA_ERR_SHAPE, "decoder_denoise: guidance > 1 needs S = 2B");
+    NOVA_REQUIRE(sp.extra_kind >= 0 && sp.extra_kind <= 2, NOVA_ERR_ARG, "decoder_denoise: extra_kind must be 0, 1 or 2");
+    const int passes = cfg ? (sp.extra_kind ? 3 : 2) : 1;
+    NOVA_REQUIRE(S >= passes * B, NOVA_ERR_SHAPE, "decoder_denoise: step %d needs %d guidance passes but S = %d, B = %d", i, passes, S, B);
     NOVA_REQUIRE(!(do_renorm && cfg) || (sp.kx == 0.f && sp.kv == 1.f && sp.cx == 1.f && sp.sigma == 0.f && sp.clip <= 0.f),
                  NOVA_ERR_ARG, "decoder_denoise: guidance renorm is built for the flow-matching Euler step only");
-    const int Se = cfg ? 2 * B : B;
+    const int Se = passes * B;
     const long rows = (long)Se * n;
     NOVA_TRY(silu_add_rows(zc, static_cast<const char*>(temb) + (size_t)i * D * es, ws_a, rows, D, dtype, st));
     NOVA_TRY(gemm_bias_act(ws_a, dec->adaln_w, dec->adaln_b, ws_mod, (int)rows, (int)mod_ld, D, NOVA_ACT_NONE, dtype, st));
@@ -324,12 +362,13 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
     }
     RowNormArgs mf{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, depth * 3 * D, depth * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
     NOVA_TRY(row_norm(mf, dtype, st));
-    const float* nz = (noise && sp.sigma != 0.f) ? noise + (size_t)i * B * n * P : nullptr;
+    const float* nz = (noise && sp.sigma != 0.f) ? noise + (size_t)i * nP : nullptr;
     if (do_renorm && cfg) {  // guidance_scaler.py:67-72: two small launches, norms over the whole sample
-      NOVA_TRY(head_cfg_step(ws_h, dec->head_w, dec->head_b, x, nullptr, ws_v, ws_v + (size_t)B * n * P, B, n, P, D, sp, 1, dtype, st));
-      NOVA_TRY(renorm_euler(x, ws_v, ws_v + (size_t)B * n * P, echo_energy, B, n, P, sp.c0, renorm, st));
+      float* extra = passes == 3 ? ws_v + 2 * nP : nullptr;
+      NOVA_TRY(head_cfg_step(ws_h, dec->head_w, dec->head_b, x, nullptr, ws_v, ws_v + nP, extra, B, n, P, D, sp, 1, dtype, st));
+      NOVA_TRY(renorm_euler(x, ws_v, ws_v + nP, extra, echo_energy, B, n, P, sp.c0, renorm, st));
     } else {
-      NOVA_TRY(head_cfg_step(ws_h, dec->head_w, dec->head_b, x, nz, nullptr, nullptr, B, n, P, D, sp, 0, dtype, st));
+      NOVA_TRY(head_cfg_step(ws_h, dec->head_w, dec->head_b, x, nz, nullptr, nullptr, nullptr, B, n, P, D, sp, 0, dtype, st));
       // guidance switched off for this step (guidance_trunc): no renorm, but the echo rows still take the Euler step
       if (do_renorm && echo_energy) NOVA_TRY(scale_vector(echo_energy, B, (1.0f + sp.c0) * (1.0f + sp.c0), st));
     }

@@ -36,9 +36,11 @@ void walk_reverse(bool on);
 bool walk_is_reverse();
 
 // ---- attn.hip
+// kv_seq_stride: elements between the first key rows of consecutive sequences (0 = Lk * kv_row_stride, i.e. packed);
+// a KV cache of capacity cap rows per sequence passes cap * kv_row_stride.
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
              long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st,
-             bool q_prescaled = false);
+             bool q_prescaled = false, long kv_seq_stride = 0);
 
 // ---- rowops.hip
 struct RowNormArgs {
@@ -75,11 +77,15 @@ int patch_embed_rows(const float* x, const void* w, const float* bias, void* out
                      int dtype, hipStream_t st);
 struct SamplerStep {  // == nova_sampler_step (include/nova_hip.h)
   float guidance, kx, kv, clip, c0, cx, sigma;
+  float extra_scale;  // 3-pass guidance: image / spatiotemporal guidance scale
+  int extra_kind;     // 0 = 2-pass, 1 = image guidance, 2 = spatiotemporal guidance (third row block of h)
 };
 int head_cfg_step(const void* h, const void* w, const float* bias, float* x, const float* noise, float* vhat, float* cond,
-                  int B, int n, int P, int D, const SamplerStep& sp, int defer, int dtype, hipStream_t st);
+                  float* extra, int B, int n, int P, int D, const SamplerStep& sp, int defer, int dtype, hipStream_t st);
 int scale_vector(float* v, int n, float f, hipStream_t st);
-int renorm_euler(float* x, const float* vhat, const float* cond, float* echo, int B, int n, int P, float dt, float renorm,
-                 hipStream_t st);
+int renorm_euler(float* x, const float* vhat, const float* cond, const float* extra, float* echo, int B, int n, int P, float dt,
+                 float renorm, hipStream_t st);
+int kv_append(const void* qkv, void* cache, int S, int Lq, int D, long cap, long base, int dtype, hipStream_t st);
+int modulate_rows(const void* x, const void* mod, void* out, long rows, int D, int dtype, hipStream_t st);
 
 }  // namespace nova

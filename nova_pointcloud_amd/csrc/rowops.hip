@@ -448,27 +448,33 @@ int patch_embed_rows(const float* x, const void* w, const float* bias, void* out
   return check_launch("patch_embed_rows");
 }
 
-// Head projection + classifier-free guidance + one sampler step for the n tokens of this AR step:
-//   pc = Wh h[b][j] + bh, pu = Wh h[B + b][j] + bh, v = cfg ? pu + g (pc - pu) : pc
+// Head projection + guidance combine + one sampler step for the n tokens of this AR step:
+//   pc = Wh h[b][j] + bh, pu = Wh h[B + b][j] + bh, (3-pass: p3 = Wh h[2B + b][j] + bh)
+//   2-pass (guidance_scaler.py:86-87):            v = pu + g (pc - pu)
+//   3-pass, image guidance (:78-81):              v = pu + g (pc - p3) + e (p3 - pu)
+//   3-pass, spatiotemporal guidance (:82-85):     v = pu + g (pc - pu) + e (pc - p3)
 //   x0 = clamp(kx x + kv v, +-clip);  x <- c0 x0 + cx x + sigma noise
 // Flow-matching Euler (scheduling_cfm.py:134-136): kx = 0, kv = 1, no clip, c0 = dt, cx = 1, sigma = 0.
 // DDPM ancestral step (scheduling_ddpm.py:236-316): kx, kv from the prediction type, c0 / cx the posterior-mean
 // coefficients, sigma the posterior std, noise the fresh gaussian of that step.
-// defer != 0 (guidance renorm): do not touch x; write v to vhat[b][j][:] and pc to cond[b][j][:] instead.
+// defer != 0 (guidance renorm): do not touch x; write the renormalised part of v (everything but the `e` term) to
+// vhat[b][j][:], pc to cond[b][j][:] and the `e` term to extra[b][j][:] (3-pass only) instead.
 template <typename T>
 __global__ __launch_bounds__(256) void head_cfg_step_kernel(const T* __restrict__ h, const T* __restrict__ w,
                                                             const float* __restrict__ bias, float* __restrict__ x,
                                                             const float* __restrict__ noise, float* __restrict__ vhat,
-                                                            float* __restrict__ cond, long rows, int B, int n, int P, int D,
-                                                            SamplerStep sp, int defer) {
+                                                            float* __restrict__ cond, float* __restrict__ extra, long rows, int B,
+                                                            int n, int P, int D, SamplerStep sp, int defer) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // b * n + j
   if (row >= rows) return;
   const int cfg = sp.guidance > 1.0f;
+  const int kind = cfg ? sp.extra_kind : 0;
   const T* hc = h + row * D;
   const T* hu = h + ((long)B * n + row) * D;
+  const T* h3 = h + ((long)2 * B * n + row) * D;
   for (int p = 0; p < P; ++p) {
-    float ac = 0.f, au = 0.f;
+    float ac = 0.f, au = 0.f, a3 = 0.f;
     for (int d = lane * 4; d < D; d += 256) {
       const f4v wv = Vec4<T>::load(w + (long)p * D + d);
       const f4v c4 = Vec4<T>::load(hc + d);
@@ -477,19 +483,32 @@ __global__ __launch_bounds__(256) void head_cfg_step_kernel(const T* __restrict_
         const f4v u4 = Vec4<T>::load(hu + d);
         au += (wv[0] * u4[0] + wv[1] * u4[1]) + (wv[2] * u4[2] + wv[3] * u4[3]);
       }
+      if (kind) {
+        const f4v t4 = Vec4<T>::load(h3 + d);
+        a3 += (wv[0] * t4[0] + wv[1] * t4[1]) + (wv[2] * t4[2] + wv[3] * t4[3]);
+      }
     }
     ac = wave_sum(ac) + bias[p];
-    float vv = ac;
+    float vv = ac, ex = 0.f;
     if (cfg) {
       au = wave_sum(au) + bias[p];
-      vv = au + (ac - au) * sp.guidance;
+      if (kind) a3 = wave_sum(a3) + bias[p];
+      if (kind == 1) {
+        vv = au + (ac - a3) * sp.guidance;
+        ex = (a3 - au) * sp.extra_scale;
+      } else {
+        vv = au + (ac - au) * sp.guidance;
+        if (kind == 2) ex = (ac - a3) * sp.extra_scale;
+      }
     }
     if (lane == 0) {
       const long e = row * P + p;
       if (defer) {
         vhat[e] = vv;
         cond[e] = ac;
+        if (extra) extra[e] = ex;
       } else {
+        vv += ex;
         const float xo = x[e];
         float x0 = sp.kx * xo + sp.kv * vv;
         if (sp.clip > 0.f) x0 = fminf(fmaxf(x0, -sp.clip), sp.clip);
@@ -502,16 +521,18 @@ __global__ __launch_bounds__(256) void head_cfg_step_kernel(const T* __restrict_
 }
 
 int head_cfg_step(const void* h, const void* w, const float* bias, float* x, const float* noise, float* vhat, float* cond,
-                  int B, int n, int P, int D, const SamplerStep& sp, int defer, int dtype, hipStream_t st) {
+                  float* extra, int B, int n, int P, int D, const SamplerStep& sp, int defer, int dtype, hipStream_t st) {
   const long rows = (long)B * n;
   if (rows <= 0) return 0;
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "head_cfg_step: D %% 4 != 0");
   if (defer && (!vhat || !cond)) return set_error(NOVA_ERR_ARG, "head_cfg_step: deferred mode needs vhat and cond buffers");
+  if (sp.extra_kind < 0 || sp.extra_kind > 2) return set_error(NOVA_ERR_ARG, "head_cfg_step: extra_kind must be 0, 1 or 2");
+  if (defer && sp.extra_kind && sp.guidance > 1.0f && !extra) return set_error(NOVA_ERR_ARG, "head_cfg_step: deferred 3-pass mode needs the extra buffer");
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
   if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(head_cfg_step_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)h, (const bf16_t*)w, bias, x, noise, vhat, cond, rows, B, n, P, D, sp, defer);
+    hipLaunchKernelGGL(head_cfg_step_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)h, (const bf16_t*)w, bias, x, noise, vhat, cond, extra, rows, B, n, P, D, sp, defer);
   else
-    hipLaunchKernelGGL(head_cfg_step_kernel<float>, grid, block, 0, st, (const float*)h, (const float*)w, bias, x, noise, vhat, cond, rows, B, n, P, D, sp, defer);
+    hipLaunchKernelGGL(head_cfg_step_kernel<float>, grid, block, 0, st, (const float*)h, (const float*)w, bias, x, noise, vhat, cond, extra, rows, B, n, P, D, sp, defer);
   return check_launch("head_cfg_step");
 }
 
@@ -519,10 +540,12 @@ int head_cfg_step(const void* h, const void* w, const float* bias, float* x, con
 // norms over ALL N rows of a sample: the n predicted rows plus the rows that merely echo the current x_t. The
 // echo rows never leave this kernel's view: their squared norm E_b is a scalar that evolves with the same step
 // (x_echo <- x_echo (1 + dt ratio)), so one block per sample reduces its n*P predicted values deterministically:
-//   ratio = clamp(sqrt((sum c^2 + E) / (sum v^2 + E)), renorm, 1);  x += dt ratio v;  E *= (1 + dt ratio)^2
+//   ratio = clamp(sqrt((sum c^2 + E) / (sum v^2 + E)), renorm, 1);  x += dt (ratio v + extra);  E *= (1 + dt ratio)^2
+// `extra` (3-pass guidance only, else null) is the term the reference adds AFTER the renormalisation
+// (guidance_scaler.py:80-81,84-85); it vanishes on the echo rows, where all passes return x_t.
 __global__ __launch_bounds__(256) void renorm_euler_kernel(float* __restrict__ x, const float* __restrict__ vhat,
-                                                          const float* __restrict__ cond, float* __restrict__ echo, int nP,
-                                                          float dt, float renorm) {
+                                                          const float* __restrict__ cond, const float* __restrict__ extra,
+                                                          float* __restrict__ echo, int nP, float dt, float renorm) {
   __shared__ float red[2][4];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* vb = vhat + (long)b * nP;
@@ -540,7 +563,7 @@ __global__ __launch_bounds__(256) void renorm_euler_kernel(float* __restrict__ x
   const float nx = sqrtf((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) + E);
   const float nc = sqrtf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + E);
   const float ratio = fminf(fmaxf(nc / nx, renorm), 1.0f);
-  for (int i = threadIdx.x; i < nP; i += 256) x[(long)b * nP + i] += dt * (ratio * vb[i]);
+  for (int i = threadIdx.x; i < nP; i += 256) x[(long)b * nP + i] += dt * (ratio * vb[i] + (extra ? extra[(long)b * nP + i] : 0.f));
   __syncthreads();
   if (threadIdx.x == 0) {
     const float f = 1.0f + dt * ratio;
@@ -559,11 +582,69 @@ int scale_vector(float* v, int n, float f, hipStream_t st) {
   return check_launch("scale_vector");
 }
 
-int renorm_euler(float* x, const float* vhat, const float* cond, float* echo, int B, int n, int P, float dt, float renorm,
-                 hipStream_t st) {
+int renorm_euler(float* x, const float* vhat, const float* cond, const float* extra, float* echo, int B, int n, int P, float dt,
+                 float renorm, hipStream_t st) {
   if (B <= 0 || n <= 0) return 0;
-  hipLaunchKernelGGL(renorm_euler_kernel, dim3(B), dim3(256), 0, st, x, vhat, cond, echo, n * P, dt, renorm);
+  hipLaunchKernelGGL(renorm_euler_kernel, dim3(B), dim3(256), 0, st, x, vhat, cond, extra, echo, n * P, dt, renorm);
   return check_launch("renorm_euler");
+}
+
+// ------------------------------------------------------------------------------------------
+// KV cache of the conditioning encoder for multi-frame generation (vision_transformer.py:55-60: k, v of the new
+// rows are concatenated behind the cached ones). The fused QKV GEMM leaves [S*Lq, 3D] rows (q | k | v); the k | v
+// part of row (s, l) is copied to cache[s][base + l][0:2D]   (cache: [S][cap][2D] per block).
+template <typename T>
+__global__ __launch_bounds__(256) void kv_append_kernel(const T* __restrict__ qkv, T* __restrict__ cache, long rows, int Lq,
+                                                        int D, long cap, long base) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const long s = row / Lq, l = row - s * Lq;
+  const T* src = qkv + row * 3 * D + D;
+  T* dst = cache + (s * cap + base + l) * 2 * D;
+  constexpr int V = 16 / sizeof(T);
+  for (int d = lane * V; d < 2 * D; d += 64 * V) *reinterpret_cast<u4v*>(dst + d) = *reinterpret_cast<const u4v*>(src + d);
+}
+
+int kv_append(const void* qkv, void* cache, int S, int Lq, int D, long cap, long base, int dtype, hipStream_t st) {
+  const long rows = (long)S * Lq;
+  if (rows <= 0) return 0;
+  const int V = dtype == NOVA_BF16 ? 8 : 4;
+  if (D % V) return set_error(NOVA_ERR_SHAPE, "kv_append: D must be a multiple of %d", V);
+  if (base < 0 || base + Lq > cap) return set_error(NOVA_ERR_SHAPE, "kv_append: rows [%ld, %ld) exceed the cache capacity %ld", base, base + Lq, cap);
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(kv_append_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)cache, rows, Lq, D, cap, base);
+  else
+    hipLaunchKernelGGL(kv_append_kernel<float>, grid, block, 0, st, (const float*)qkv, (float*)cache, rows, Lq, D, cap, base);
+  return check_launch("kv_append");
+}
+
+// out[r][:] = x[r][:] * (1 + mod[r][0:D]) + mod[r][D:2D]   (AdaLayerNorm with eps=None, i.e. no normalisation: the
+// frame mixer of the conditioning encoder, normalization.py:41-46 + transformer_nova.py:87-89)
+template <typename T>
+__global__ __launch_bounds__(256) void modulate_rows_kernel(const T* __restrict__ x, const T* __restrict__ mod, T* __restrict__ out,
+                                                            long total4, int D) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long e = i * 4;
+    const long r = e / D;
+    const int d = (int)(e - r * D);
+    const f4v xv = Vec4<T>::load(x + e);
+    const f4v sc = Vec4<T>::load(mod + r * 2 * D + d), sh = Vec4<T>::load(mod + r * 2 * D + D + d);
+    Vec4<T>::store(out + e, xv * (1.0f + sc) + sh);
+  }
+}
+
+int modulate_rows(const void* x, const void* mod, void* out, long rows, int D, int dtype, hipStream_t st) {
+  if (rows <= 0) return 0;
+  if (D % 4) return set_error(NOVA_ERR_SHAPE, "modulate_rows: D %% 4 != 0");
+  const long total4 = rows * D / 4;
+  const int blocks = (int)((total4 + 255) / 256 > 8192 ? 8192 : (total4 + 255) / 256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(modulate_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)mod, (bf16_t*)out, total4, D);
+  else
+    hipLaunchKernelGGL(modulate_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)mod, (float*)out, total4, D);
+  return check_launch("modulate_rows");
 }
 
 }  // namespace nova

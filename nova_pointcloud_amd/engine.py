@@ -101,7 +101,9 @@ class _Guidance(object):
         self.guidance_scale = inputs.get("guidance_scale", 1)
         self.guidance_trunc = inputs.get("guidance_trunc", 0)
         self.guidance_renorm = inputs.get("guidance_renorm", 1)
-        self.extra_pass = inputs.get("image_guidance_scale", 0) + inputs.get("spatiotemporal_guidance_scale", 0) > 0
+        self.image_guidance_scale = inputs.get("image_guidance_scale", 0) or 0
+        self.spatiotemporal_guidance_scale = inputs.get("spatiotemporal_guidance_scale", 0) or 0
+        self.extra_pass = self.image_guidance_scale + self.spatiotemporal_guidance_scale > 0
         self.min_guidance_scale = inputs.get("min_guidance_scale", None) or self.guidance_scale
         self.inc_guidance_scale = self.guidance_scale - self.min_guidance_scale
 
@@ -205,6 +207,7 @@ class NovaEngine(object):
         self.vnorm = (pk.f(ve.norm.weight), pk.f(ve.norm.bias))
         self.inorm = (pk.f(ie.norm.weight), pk.f(ie.norm.bias))
         self.patch = (pk.w(patch_weight(ie.patch_embed.proj), dtype), pk.f(ie.patch_embed.proj.bias))
+        self.vpatch = (pk.w(patch_weight(ve.patch_embed.proj), dtype), pk.f(ve.patch_embed.proj.bias))  # frames t > 0
         self.mask_token = pk.w(m.mask_embed.mask_token, dtype)
         self.time_freq = torch.arange(128, dtype=_F32, device=dev).mul(-9.210340371976184 / 128).exp()
         self.vtime = None
@@ -267,7 +270,7 @@ class NovaEngine(object):
         hip.call("nova_qkv_rope_cols", x2.data_ptr(), lp.kv[0], lp.kv[1], hip.ptr(rope_full), kv.data_ptr(), S * L, 2 * D, D,
                  L, 1, hd, D, code, st())
         # the predicted rows of every sequence (cond and uncond share pred_ids)
-        ids = torch.cat([pred_ids] * (S // B)).contiguous()  # [S, n]
+        ids = torch.cat([pred_ids] * (S // B)).contiguous()  # [S, n]: every guidance pass predicts the same tokens
         xq = torch.empty(S * n, D, dtype=x2.dtype, device=x2.device)
         hip.call("nova_build_sequence", None, 0, x2.data_ptr() + Nv * D * es, L, ids.data_ptr(), xq.data_ptr(), S, S, 0, n, D,
                  code, st())
@@ -298,21 +301,30 @@ class NovaEngine(object):
     # ------------------------------------------------------------------ the generation loop
     @torch.no_grad()
     def generate(self, inputs):
-        """Eval-mode `Transformer3DModel.forward` body for max_latent_length == 1. Returns x [B,C,1,H,W].
+        """Eval-mode `Transformer3DModel.forward` body (transformer_3d.py:63-77,102-164,192-200). Returns x [B,C,T,H,W]
+        (T = max_latent_length; a point set is the T = 1 case).
 
         The batch may be run as two half-batch LANES on two HIP streams (`inputs["lanes"]`, default 2 for B >= 4):
         samples are independent, so while one lane is in its latency-bound denoise loop (hundreds of small launches)
         the other lane's encoder GEMMs fill the idle CUs. All random draws stay here, for the whole batch and in the
         reference's order, and the lanes receive row slices - results do not depend on the number of lanes.
         """
-        m = self.model
         self._refresh()
+        with torch.cuda.device(self.dev):  # launches go to the model's device whatever the caller's current device is
+            return self._generate(inputs)
+
+    def _generate(self, inputs):
+        m = self.model
         dev, dtype = self.dev, self.dtype
         scaler = _Guidance(inputs)
-        if scaler.extra_pass:
-            raise NotImplementedError("3-pass (image / spatiotemporal) guidance is a video feature: not built on the HIP path")
-        if inputs.get("max_latent_length", 1) != 1:
-            raise NotImplementedError("max_latent_length > 1 (video, KV-cached frames) is not built on the HIP path")
+        if scaler.image_guidance_scale and scaler.spatiotemporal_guidance_scale:
+            raise ValueError("image_guidance_scale and spatiotemporal_guidance_scale are exclusive (the reference's expand_text "
+                             "builds four text blocks for three guidance passes when both are set, guidance_scaler.py:46-57)")
+        if m.text_embed is None:
+            raise NotImplementedError("label-conditioned models (text_embed = None) are not built on the HIP path")
+        if inputs.get("c", None):
+            raise NotImplementedError("a pre-supplied condition list inputs['c'] is not built on the HIP path")
+        T = int(inputs.get("max_latent_length", 1))
         ie, ve = m.image_encoder, m.video_encoder
         C, (H, W), p = ie.image_dim, ie.image_size, ie.patch_embed.patch_size
         h, w = H // p, W // p
@@ -320,9 +332,10 @@ class NovaEngine(object):
         prompt = inputs["prompt"]
         if isinstance(prompt, (tuple, list)):  # strings or per-prompt embeddings: host-side padding (embeddings.py:179-201)
             prompt = m.text_embed.encode_prompts(prompt)
-        S = prompt.shape[0]
+        S0 = prompt.shape[0]
         cfg_on = scaler.guidance_scale > 1
-        B = S // 2 if cfg_on else S
+        passes = (3 if scaler.extra_pass else 2) if cfg_on else 1
+        B = S0 // 2 if cfg_on else S0
         generator = inputs.get("generator", None)
         host_rng = generator is not None and generator.device.type == "cpu"
         rng_dev = "cpu" if host_rng else dev
@@ -331,12 +344,28 @@ class NovaEngine(object):
         if scaler.guidance_renorm < 1 and ancestral:
             raise NotImplementedError("guidance_renorm < 1 with an ancestral sampler is not built on the HIP path")
         num_preds = [int(v) for v in inputs["num_preds"] if v > 0]
-        latents = inputs.get("latents", [])
-        if latents:  # prefilled first frame with max_latent_length == 1: nothing to generate (transformer_3d.py:159-160)
-            return torch.stack([latents[-1].to(device=dev, dtype=dtype)], dim=2)
+        latents = list(inputs.get("latents", []) or [])
+        prefilled = bool(latents)  # first frame given (image-to-video): frame 0 is not generated (transformer_3d.py:159-160)
+        gen_frames = [t for t in range(T) if not (t == 0 and prefilled)]
+        if not gen_frames:
+            return torch.stack([v.to(device=dev, dtype=dtype) for v in latents], dim=2)
+
+        # ---- condition rows of every guidance pass: [cond ; uncond ; third] (guidance_scaler.py:46-57 expand_text)
+        prompt = prompt.to(device=dev, dtype=dtype)
+        motion = None
+        if m.motion_embed is not None and inputs.get("motion_flow", None) is not None:  # transformer_3d.py:72-75
+            flow, fps = inputs.get("motion_flow"), inputs.get("fps", None)
+            rep = 2 if cfg_on else 1
+            flow = list(flow) * rep if flow else [m.motion_embed.base_flow] * S0
+            fps = list(fps) * rep if fps else [m.motion_embed.base_fps] * S0
+            motion = torch.tensor([flow, fps], dtype=_F32).t().contiguous()  # [S0, 2]
+        if passes == 3:
+            third = slice(B, 2 * B) if scaler.image_guidance_scale else slice(0, B)
+            prompt = torch.cat([prompt, prompt[third]])
+            motion = torch.cat([motion, motion[third]]) if motion is not None else None
 
         # ---- random draws for the WHOLE batch, in the reference's order (embeddings.py:265; transformer_3d.py:131).
-        # Batch-sharded runs (sharding.py, SURVEY §8e) pass batch_shard = (lo, hi, total): every rank then draws the
+        # Batch-sharded runs (sharding.py, SURVEY section 8e) pass batch_shard = (lo, hi, total): every rank then draws the
         # tensors of the GLOBAL batch from the same seed and keeps its rows, so sharded(seed) == unsharded(seed).
         g_lo, g_hi, g_B = inputs.get("batch_shard", None) or (0, B, B)
         if g_hi - g_lo != B or not (0 <= g_lo <= g_hi <= g_B):
@@ -347,22 +376,21 @@ class NovaEngine(object):
             order = u[g_lo:g_hi].argsort(dim=1)[..., 0]
         order = order.to(dev).contiguous()
         m.mask_embed.pred_ids = order.unsqueeze(-1)
-        noise_fn = inputs.get("noise_fn", None)  # test hook: replay recorded per-step noise
+        noise_fn = inputs.get("noise_fn", None)  # test hook: replay recorded per-step noise (index: running AR step)
         noise_buf = torch.empty(g_B, C, H, W, dtype=_F32, device=rng_dev)
+        to_rows = lambda t: t.to(dev).reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P)
 
-        def draw(i, n):
+        def draw(i):
             """Per-AR-step draws: x_T canvas [B,N,P] and, for an ancestral sampler, one gaussian canvas per step with t > 0."""
             if noise_fn is not None:
                 nz = noise_fn(i).to(_F32)
             else:
                 nz = noise_buf.normal_(generator=generator)[g_lo:g_hi]
-            nz = nz.to(dev).reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P)
             extra = None
             if ancestral:  # scheduling_ddpm.py:303-305
-                extra = [torch.randn(g_B, C, H, W, generator=generator, device=rng_dev, dtype=_F32)[g_lo:g_hi].to(dev)
-                         .reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P) if coefs[j][5] != 0.0 else None
-                         for j in range(steps)]
-            return nz, extra
+                extra = [to_rows(torch.randn(g_B, C, H, W, generator=generator, device=rng_dev, dtype=_F32)[g_lo:g_hi])
+                         if coefs[j][5] != 0.0 else None for j in range(steps)]
+            return to_rows(nz), extra
 
         # measured (MI355X): two lanes +6 % at batch 8 (d48w768 / 1024 points) and +3 % at batch 32 (d48w1024 / 2048 points)
         # once the encoder GEMMs are persistent (one lane's row kernels, decoder launches and epilogue store bursts fill
@@ -371,13 +399,15 @@ class NovaEngine(object):
         lanes = max(1, min(lanes, B))
         main = torch.cuda.current_stream()
         bounds = [(B * k // lanes, B * (k + 1) // lanes) for k in range(lanes)]
-        prompt = prompt.to(device=dev, dtype=dtype)
+        first = latents[-1].to(device=dev, dtype=_F32) if prefilled else None
         runs = []
         for k, (lo, hi) in enumerate(bounds):
-            rows = torch.cat([prompt[lo:hi], prompt[B + lo:B + hi]]) if cfg_on else prompt[lo:hi]
+            pick = lambda t: torch.cat([t[q * B + lo:q * B + hi] for q in range(passes)]).contiguous()
             stream = main if lanes == 1 else self._lane_stream(k)
-            ctx = dict(k=k, lo=lo, hi=hi, prompt=rows.contiguous(), order=order[lo:hi].contiguous(), stream=stream, inbox=None)
-            runs.append((ctx, self._lane(ctx, inputs, scaler_args=inputs, timesteps=timesteps, coefs=coefs, ancestral=ancestral,
+            ctx = dict(k=k, lo=lo, hi=hi, prompt=pick(prompt), motion=None if motion is None else pick(motion),
+                       order=order[lo:hi].contiguous(), stream=stream, inbox=None, frames=[],
+                       first=None if first is None else first[lo:hi])
+            runs.append((ctx, self._lane(ctx, inputs, T=T, passes=passes, timesteps=timesteps, coefs=coefs, ancestral=ancestral,
                                          num_preds=num_preds, cfg_on=cfg_on)))
 
         def advance(ctx, gen):
@@ -387,27 +417,36 @@ class NovaEngine(object):
                     return next(gen, None)
             return next(gen, None)
 
-        for ctx, gen in runs:  # prefix + conditioning encoder
-            advance(ctx, gen)
-        for i, n in enumerate(num_preds):
-            nz, extra = draw(i, n)
-            for ctx, gen in runs:
-                lo, hi = ctx["lo"], ctx["hi"]
-                ctx["inbox"] = (nz[lo:hi], None if extra is None else [None if e is None else e[lo:hi] for e in extra])
-                if lanes > 1:  # tensors made on the main stream, consumed on the lane's stream
-                    nz.record_stream(ctx["stream"])
-                    [e.record_stream(ctx["stream"]) for e in (extra or []) if e is not None]
+        step_no = 0
+        for t in range(T):
+            for ctx, gen in runs:  # condition prefix (t = 0) + conditioning encoder of frame t
                 advance(ctx, gen)
-        canvas = torch.empty(B, N, P, dtype=_F32, device=dev)
+            if t not in gen_frames:
+                continue
+            for n in num_preds:
+                nz, extra = draw(step_no)
+                step_no += 1
+                for ctx, gen in runs:
+                    lo, hi = ctx["lo"], ctx["hi"]
+                    ctx["inbox"] = (nz[lo:hi], None if extra is None else [None if e is None else e[lo:hi] for e in extra])
+                    if lanes > 1:  # tensors made on the main stream, consumed on the lane's stream
+                        nz.record_stream(ctx["stream"])
+                        [e.record_stream(ctx["stream"]) for e in (extra or []) if e is not None]
+                    advance(ctx, gen)
+        nf = len(runs[0][0]["frames"])
+        canvas = torch.empty(nf, B, N, P, dtype=_F32, device=dev)
         mask = torch.empty(B, N, dtype=_F32, device=dev)
         for ctx, gen in runs:
             if lanes > 1:
                 main.wait_stream(ctx["stream"])
-            canvas[ctx["lo"]:ctx["hi"]] = ctx["canvas"]
+            for f in range(nf):
+                canvas[f, ctx["lo"]:ctx["hi"]] = ctx["frames"][f]
             mask[ctx["lo"]:ctx["hi"]] = ctx["mask"]
         m.mask_embed.mask, m.mask_embed.pred_pos = mask.unsqueeze(-1).to(dtype), sum(num_preds)
-        x = canvas.reshape(B, h, w, p, p, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, H, W)
-        return x.to(dtype).unsqueeze(2)
+        x = canvas.reshape(nf, B, h, w, p, p, C).permute(1, 6, 0, 2, 4, 3, 5).reshape(B, C, nf, H, W).to(dtype)
+        if prefilled:  # the given frames stay in the output list ahead of the generated ones (transformer_3d.py:139,163)
+            x = torch.cat([torch.stack([v.to(device=dev, dtype=dtype) for v in latents], dim=2), x], dim=2)
+        return x
 
     def _lane_stream(self, k):
         pool = self.__dict__.setdefault("_streams", {})
@@ -415,119 +454,205 @@ class NovaEngine(object):
             pool[(k, self.dev)] = torch.cuda.Stream(device=self.dev)
         return pool[(k, self.dev)]
 
-    def _lane(self, ctx, inputs, scaler_args, timesteps, coefs, ancestral, num_preds, cfg_on):
+    def _motion_tokens(self, values):
+        """MotionEmbed.forward (embeddings.py:119-137): [S, 2] (flow, fps) -> two condition tokens per row [S, 2, D]."""
+        me = self.model.motion_embed
+        cache = self.misc.__dict__.setdefault("motion", None)
+        if cache is None:
+            pk = self.misc
+            cache = self.misc.motion = [(pk.w(pr[0].weight, self.dtype), pk.f(pr[0].bias), pk.w(pr[2].weight, self.dtype), pk.f(pr[2].bias))
+                                        for pr in (me.flow_proj, me.fps_proj)]
+        toks = []
+        for col, (w1, b1, w2, b2) in enumerate(cache):
+            ang = values[:, col].reshape(-1, 1).float() * me.freq_m.reshape(1, -1)
+            feats = torch.cat([ang.sin(), ang.cos()], dim=-1).to(device=self.dev, dtype=self.dtype).contiguous()
+            toks.append(self._gemm(self._gemm(feats, w1, b1, self.D, hip.ACT_SILU), w2, b2, self.D))
+        return torch.stack(toks, dim=1)
+
+    def _mixer(self, first, cur):
+        """`video_encoder.mixer(states['*'], c)` (transformer_3d.py:156-158): AdaLayerNorm with eps=None, i.e.
+        first * (1 + scale) + shift with (scale, shift) = proj(lora(SiLU(cur))) (normalization.py:33-36,41-46)."""
+        mx = self.model.video_encoder.mixer
+        pk = self.misc
+        cache = pk.__dict__.get("mixer", None)
+        if cache is None:
+            lora = None if isinstance(mx.lora, torch.nn.Identity) else pk.w(mx.lora.weight, self.dtype)
+            cache = pk.mixer = (lora, mx.lora.weight.shape[0] if lora else 0, pk.w(mx.proj.weight, self.dtype), pk.f(mx.proj.bias))
+            if not isinstance(mx.norm, torch.nn.Identity):
+                raise NotImplementedError("a normalising video mixer (eps != None) is not built on the HIP path")
+        lora, rank, pw, pb = cache
+        act = torch.empty_like(cur)
+        hip.call("nova_silu_add_rows", cur.data_ptr(), None, act.data_ptr(), cur.shape[0], self.D, self.code, hip.stream_ptr())
+        if lora:
+            if rank % 128:
+                raise NotImplementedError(f"video mixer rank {rank} is not a multiple of 128 (GEMM tile width)")
+            act = self._gemm(act, lora, None, rank)
+        mod = self._gemm(act, pw, pb, 2 * self.D)
+        out = torch.empty_like(first)
+        hip.call("nova_modulate_rows", first.data_ptr(), mod.data_ptr(), out.data_ptr(), first.shape[0], self.D, self.code,
+                 hip.stream_ptr())
+        return out
+
+    def _lane(self, ctx, inputs, T, passes, timesteps, coefs, ancestral, num_preds, cfg_on):
         """Generator: the generation loop for the samples [lo, hi) of the batch. Yields after the conditioning encoder
-        and after every AR step (the caller alternates lanes and feeds this step's noise rows through ctx["inbox"])."""
+        of every frame and after every AR step (the caller alternates lanes and feeds this step's noise rows through
+        ctx["inbox"])."""
         m = self.model
         dev, dtype, D = self.dev, self.dtype, self.D
-        scaler = _Guidance(scaler_args)
+        scaler = _Guidance(inputs)
         ie, ve = m.image_encoder, m.video_encoder
         C, (H, W), p = ie.image_dim, ie.image_size, ie.patch_embed.patch_size
         h, w = H // p, W // p
         pv = ve.patch_embed.patch_size
         hv, wv = H // pv, W // pv
-        N, Nv, P = h * w, hv * wv, p * p * C
+        N, Nv, P, Pv = h * w, hv * wv, p * p * C, pv * pv * C
         prompt = ctx["prompt"]
         S, Lt = prompt.shape[0], prompt.shape[1]
-        B = S // 2 if cfg_on else S
+        B = S // passes
         steps = len(timesteps)
         renorm = float(scaler.guidance_renorm)
         nmax = max(num_preds) if num_preds else 1
+        Lp = Lt + (2 if ctx["motion"] is not None else 0)  # condition prefix: text tokens (+ flow and fps tokens)
         L2 = Nv + N
-        ws = self._workspace(S, B, N, max(L2, Lt + Nv), nmax, ctx["k"])
+        ws = self._workspace(S, B, N, max(L2, Lp + Nv), nmax, ctx["k"])
         code, st = self.code, hip.stream_ptr
+        extra_kind = (1 if scaler.image_guidance_scale else 2) if passes == 3 else 0
+        extra_scale = float(scaler.image_guidance_scale or scaler.spatiotemporal_guidance_scale) if passes == 3 else 0.0
 
-        # ---- text prefix: TextEmbed.forward (embeddings.py:203-206)
+        # ---- condition prefix: TextEmbed.forward (embeddings.py:203-206) [+ MotionEmbed tokens, transformer_3d.py:72-75]
         pr = prompt.reshape(S * Lt, -1).contiguous()
         c_txt = self._norm_rows(self._gemm(pr, self.text[0], self.text[1], D), self.text[2:])
+        if ctx["motion"] is not None:
+            c_txt = torch.cat([c_txt.view(S, Lt, D), self._motion_tokens(ctx["motion"])], dim=1).reshape(S * Lp, D).contiguous()
         temb = self.timestep_table(timesteps)
 
-        # ---- conditioning ViT over [text ; bos canvas] (transformer_3d.py:151-155)
-        vtok = m.mask_embed.bos_token.detach().to(dtype).expand(Nv, D)
-        rope_v = rope_i = pos_img = inv_freq = img_pe = None
+        # ---- positions / absolute position tables
+        rope_i = pos_img = inv_freq = inv_freq_v = img_pe = vpos = None
         hd = D // self.heads
-        if m.image_pos_embed is not None:
-            pos_v = m.video_pos_embed.get_pos(1)[0].to(device=dev, dtype=_F32).contiguous()
+        rotary = m.image_pos_embed is not None
+        if rotary:
+            vpos = m.video_pos_embed.get_pos(T)[0].to(device=dev, dtype=_F32).reshape(T, Nv, 3).contiguous()  # frame t: (t, h, w)
             pos_img = m.image_pos_embed.get_pos(1)[0].to(device=dev, dtype=_F32).contiguous()
             inv_freq = m.image_pos_embed.inv_freq().to(device=dev, dtype=_F32).contiguous()
             inv_freq_v = m.video_pos_embed.inv_freq().to(device=dev, dtype=_F32).contiguous()
-            rope_v = hip.rope_table(pos_v, None, Lt, inv_freq_v, 1, hd)
             rope_i = hip.rope_table(pos_img, None, Nv, inv_freq, 1, hd)
-        else:  # abs-PE: bos + time_embed[0] + sincos (transformer_3d.py:154, embeddings.py:113-115)
+        else:  # abs-PE: tokens + time_embed[t] + sincos (transformer_3d.py:154, embeddings.py:103-115)
             vpe = m.video_pos_embed
-            ang = torch.zeros(1, 1, dtype=_F32) * vpe.freq_t  # frame index 0 of T = 1 (embeddings.py:103-111)
-            feats = torch.cat([ang.sin(), ang.cos()], dim=-1).to(device=dev, dtype=dtype)
+            frame = (torch.arange(T, dtype=_F32) / (T / vpe.base_t)).view(-1, 1)
+            ang = frame * vpe.freq_t.reshape(1, -1)
+            feats = torch.cat([ang.sin(), ang.cos()], dim=-1).to(device=dev, dtype=dtype).contiguous()
             w1, b1, w2, b2, g, bt = self.vtime
-            t_emb = self._norm_rows(self._gemm(self._gemm(feats, w1, b1, D, hip.ACT_SILU), w2, b2, D), (g, bt))
-            vtok = vtok + t_emb + vpe.get_space_embed(dev, dtype)
+            t_emb = self._norm_rows(self._gemm(self._gemm(feats, w1, b1, D, hip.ACT_SILU), w2, b2, D), (g, bt))  # [T, D]
+            v_pe = vpe.get_space_embed(dev, dtype)  # [Nv, D]
             img_pe = ie.pos_embed.get_space_embed(dev, dtype).contiguous()
-        vtok = vtok.contiguous()
-        Lv = Lt + Nv
-        xv = ws["x1"][: S * Lv]
-        self._sequence(xv, c_txt, Lt, vtok, 0, None, S, B, Lt, Nv)
-        self._blocks(self.video, xv, S, Lv, rope_v, 1, ws)
+        bos = m.mask_embed.bos_token.detach().to(dtype)
         ar = torch.arange(S, device=dev, dtype=torch.int32)
-        vrows = (ar[:, None] * Lv + Lt + torch.arange(Nv, device=dev, dtype=torch.int32)[None]).reshape(-1).contiguous()
-        c = self._norm_rows(xv, self.vnorm, gather=vrows)  # [S*Nv, D]
-
-        # ---- masked autoregressive loop (transformer_3d.py:115-133)
-        canvas = torch.zeros(B, N, P, dtype=_F32, device=dev)
-        mask = torch.ones(B, N, dtype=_F32, device=dev)
+        cache = cap = None
+        if T > 1:  # KV cache of the conditioning encoder (vision_transformer.py:55-60,125-126): prefix + T frames of Nv tokens
+            cap = Lp + T * Nv
+            cache = torch.empty(len(self.video.arr), S, cap, 2 * D, dtype=dtype, device=dev)
+        mixing = T > 1 and not isinstance(ve.mixer, torch.nn.Identity)
+        c_first = None
+        canvas = ctx["first"]
+        if canvas is not None:  # prefilled first frame [b, C, H, W] -> patch rows [b, N, P]
+            canvas = canvas.reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P).contiguous()
         order = ctx["order"]
-        ctx["canvas"], ctx["mask"] = canvas, mask
-        yield "prefix"
-        done = 0
-        for i, n in enumerate(num_preds):
-            scaler.decay_guidance_scale((i + 1) / len(num_preds))
-            if cfg_on and scaler.guidance_scale <= 1:
-                raise NotImplementedError("guidance decaying to <= 1 inside a CFG run is undefined in the reference")
-            plan = (hip.SamplerStep * steps)()
-            for j, t in enumerate(timesteps):
-                g = 1.0 if (cfg_on and scaler.guidance_trunc and float(t) < scaler.guidance_trunc) else float(scaler.guidance_scale)
-                plan[j] = hip.SamplerStep(g if cfg_on else 1.0, *coefs[j])
-            z0 = ws["z0"]
-            hip.call("nova_embed_canvas", canvas.data_ptr(), mask.data_ptr(), self.patch[0], self.patch[1], self.mask_token,
-                     hip.ptr(img_pe), z0.data_ptr(), B, N, P, D, code, st())
-            prev_ids = order[:, :done].contiguous()
-            pred_ids = order[:, done : done + n].contiguous()
-            mask.scatter_(1, pred_ids, 0.0)
-            # first half: [c ; known tokens in generation order]
-            L1 = Nv + done
-            x1 = ws["x1"][: S * L1]
-            self._sequence(x1, c, Nv, z0, N, prev_ids if done else None, S, B, Nv, done)
-            rope1 = hip.rope_table(pos_img, prev_ids, Nv, inv_freq, B, hd) if (pos_img is not None and done) else (
-                rope_i[:, :Nv].contiguous() if pos_img is not None else None)
-            self._blocks(self.enc1, x1, S, L1, rope1, B if (pos_img is not None and done) else 1, ws)
-            # second half: [c' ; full canvas with the known tokens scattered back]
-            x2 = ws["x2"][: S * L2]
-            self._sequence(x2, x1, L1, z0, N, None, S, B, Nv, N)
-            if done:
-                hip.call("nova_scatter_tokens", x1.data_ptr(), prev_ids.data_ptr(), x2.data_ptr(), S, B, Nv, N, done, D, code, st())
-            if self.enc2_head is not None:
-                self._blocks(self.enc2_head, x2, S, L2, rope_i, 1, ws)
-            y = self._last_block_rows(x2, S, B, L2, Nv, n, pred_ids, pos_img, inv_freq, rope_i, hd, ws)
-            # final LN only on the rows predicted now, then the condition projection (time term added per step)
-            zc = self._norm_rows(y, self.inorm)
-            w1, b1, w2, b2 = self.dec.time[1]
-            zc = self._gemm(self._gemm(zc, w1, b1, D, hip.ACT_SILU), w2, b2, D)
-            # this step's noise rows (drawn by the caller for the whole batch)
-            nz, extra = ctx["inbox"]
-            idx = pred_ids[..., None].expand(-1, -1, P)
-            x_n = nz.gather(1, idx).contiguous()
-            step_noise = echo = ws_v = None
-            if ancestral:
-                step_noise = torch.stack([torch.zeros(B, n, P, dtype=_F32, device=dev) if e is None else e.gather(1, idx)
-                                          for e in extra]).contiguous()
-            if renorm < 1 and cfg_on:  # squared norm of the rows that only echo x_t in the reference (guidance_scaler.py:67-72)
-                echo = (nz.pow(2).sum((1, 2)) - x_n.pow(2).sum((1, 2))).clamp_min(0).contiguous()
-                ws_v = torch.empty(2 * B * n * P, dtype=_F32, device=dev)
-            hip.call("nova_decoder_denoise", ctypes.byref(self.dec.struct), zc.data_ptr(), temb.data_ptr(), x_n.data_ptr(), plan,
-                     hip.ptr(step_noise), renorm if cfg_on else 1.0, hip.ptr(echo), steps, S, B, n, P, D, ws["da"].data_ptr(),
-                     ws["du"].data_ptr(), ws["dh"].data_ptr(), ws["df"].data_ptr(), ws["dg"].data_ptr(), ws["dmod"].data_ptr(),
-                     hip.ptr(ws_v), code, st())
-            canvas.scatter_(1, idx, x_n)
-            done += n
-            yield i
+
+        for t in range(T):
+            # ---- conditioning ViT of frame t (transformer_3d.py:150-158)
+            if t == 0:
+                vtok = bos.expand(Nv, D)
+                if not rotary:
+                    vtok = vtok + t_emb[0] + v_pe
+                vtok = vtok.contiguous()
+                Lq, pad = Lp + Nv, Lp
+                xv = ws["x1"][: S * Lq]
+                self._sequence(xv, c_txt, Lp, vtok, 0, None, S, B, Lp, Nv)
+            else:  # patch embedding (patch 2p) of the previous frame
+                img = canvas.reshape(B, h, w, p, p, C).permute(0, 5, 1, 3, 2, 4).reshape(B, C, H, W)
+                rows = img.reshape(B, C, hv, pv, wv, pv).permute(0, 2, 4, 3, 5, 1).reshape(B, Nv, Pv).contiguous()
+                Lq, pad = Nv, 0
+                xv = ws["x1"][: S * Lq]
+                hip.call("nova_patch_embed_rows", rows.data_ptr(), self.vpatch[0], self.vpatch[1], xv.data_ptr(), S, B, Nv, Pv, D, code, st())
+                if not rotary:
+                    xv.view(S, Nv, D).add_(t_emb[t] + v_pe)
+            if extra_kind == 1:  # image guidance: the uncond pass sees bare bos tokens (expand(c, padding=bos), guidance_scaler.py:42-43)
+                xv.view(S, Lq, D)[B:2 * B, pad:] = bos
+            rope_v = hip.rope_table(vpos[t].contiguous(), None, pad, inv_freq_v, 1, hd) if rotary else None
+            if cache is None:
+                self._blocks(self.video, xv, S, Lq, rope_v, 1, ws)
+            else:
+                hip.call("nova_vit_blocks_forward_kv", self.video.arr, len(self.video.arr), xv.data_ptr(), S, Lq, D, self.heads,
+                         self.hidden, hip.ptr(rope_v), 1, cache.data_ptr(), cap, 0 if t == 0 else Lp + t * Nv,
+                         ws["qkv"].data_ptr(), ws["a"].data_ptr(), ws["b"].data_ptr(), ws["h"].data_ptr(), code, st())
+            vrows = (ar[:, None] * Lq + pad + torch.arange(Nv, device=dev, dtype=torch.int32)[None]).reshape(-1).contiguous()
+            c = self._norm_rows(xv, self.vnorm, gather=vrows)  # [S*Nv, D]
+            if mixing:
+                c_first = c if t == 0 else c_first
+                c = self._mixer(c_first, c) if t else c
+            if t == 0 and canvas is not None:  # prefilled first frame: nothing to generate
+                yield "prefix"
+                continue
+
+            # ---- masked autoregressive loop of frame t (transformer_3d.py:115-133)
+            canvas = torch.zeros(B, N, P, dtype=_F32, device=dev)
+            mask = torch.ones(B, N, dtype=_F32, device=dev)
+            ctx["mask"] = mask
+            yield "prefix"
+            done = 0
+            for i, n in enumerate(num_preds):
+                scaler.decay_guidance_scale((i + 1) / len(num_preds))
+                if cfg_on and scaler.guidance_scale <= 1:
+                    raise NotImplementedError("guidance decaying to <= 1 inside a CFG run is undefined in the reference")
+                plan = (hip.SamplerStep * steps)()
+                for j, tt in enumerate(timesteps):
+                    g = 1.0 if (cfg_on and scaler.guidance_trunc and float(tt) < scaler.guidance_trunc) else float(scaler.guidance_scale)
+                    plan[j] = hip.SamplerStep(g if cfg_on else 1.0, *coefs[j], extra_scale, extra_kind)
+                z0 = ws["z0"]
+                hip.call("nova_embed_canvas", canvas.data_ptr(), mask.data_ptr(), self.patch[0], self.patch[1], self.mask_token,
+                         hip.ptr(img_pe), z0.data_ptr(), B, N, P, D, code, st())
+                prev_ids = order[:, :done].contiguous()
+                pred_ids = order[:, done : done + n].contiguous()
+                mask.scatter_(1, pred_ids, 0.0)
+                # first half: [c ; known tokens in generation order]
+                L1 = Nv + done
+                x1 = ws["x1"][: S * L1]
+                self._sequence(x1, c, Nv, z0, N, prev_ids if done else None, S, B, Nv, done)
+                rope1 = hip.rope_table(pos_img, prev_ids, Nv, inv_freq, B, hd) if (rotary and done) else (
+                    rope_i[:, :Nv].contiguous() if rotary else None)
+                self._blocks(self.enc1, x1, S, L1, rope1, B if (rotary and done) else 1, ws)
+                # second half: [c' ; full canvas with the known tokens scattered back]
+                x2 = ws["x2"][: S * L2]
+                self._sequence(x2, x1, L1, z0, N, None, S, B, Nv, N)
+                if done:
+                    hip.call("nova_scatter_tokens", x1.data_ptr(), prev_ids.data_ptr(), x2.data_ptr(), S, B, Nv, N, done, D, code, st())
+                if self.enc2_head is not None:
+                    self._blocks(self.enc2_head, x2, S, L2, rope_i, 1, ws)
+                y = self._last_block_rows(x2, S, B, L2, Nv, n, pred_ids, pos_img, inv_freq, rope_i, hd, ws)
+                # final LN only on the rows predicted now, then the condition projection (time term added per step)
+                zc = self._norm_rows(y, self.inorm)
+                w1, b1, w2, b2 = self.dec.time[1]
+                zc = self._gemm(self._gemm(zc, w1, b1, D, hip.ACT_SILU), w2, b2, D)
+                # this step's noise rows (drawn by the caller for the whole batch)
+                nz, extra = ctx["inbox"]
+                idx = pred_ids[..., None].expand(-1, -1, P)
+                x_n = nz.gather(1, idx).contiguous()
+                step_noise = echo = ws_v = None
+                if ancestral:
+                    step_noise = torch.stack([torch.zeros(B, n, P, dtype=_F32, device=dev) if e is None else e.gather(1, idx)
+                                              for e in extra]).contiguous()
+                if renorm < 1 and cfg_on:  # squared norm of the rows that only echo x_t in the reference (guidance_scaler.py:67-72)
+                    echo = (nz.pow(2).sum((1, 2)) - x_n.pow(2).sum((1, 2))).clamp_min(0).contiguous()
+                    ws_v = torch.empty(3 * B * n * P, dtype=_F32, device=dev)
+                hip.call("nova_decoder_denoise", ctypes.byref(self.dec.struct), zc.data_ptr(), temb.data_ptr(), x_n.data_ptr(), plan,
+                         hip.ptr(step_noise), renorm if cfg_on else 1.0, hip.ptr(echo), steps, S, B, n, P, D, ws["da"].data_ptr(),
+                         ws["du"].data_ptr(), ws["dh"].data_ptr(), ws["df"].data_ptr(), ws["dg"].data_ptr(), ws["dmod"].data_ptr(),
+                         hip.ptr(ws_v), code, st())
+                canvas.scatter_(1, idx, x_n)
+                done += n
+                if i == len(num_preds) - 1:
+                    ctx["frames"].append(canvas)
+                yield i
 
 
 # --------------------------------------------------------------------------------------------

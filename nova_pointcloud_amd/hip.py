@@ -50,7 +50,7 @@ class Decoder(ctypes.Structure):
 class SamplerStep(ctypes.Structure):
     """``nova_sampler_step`` (include/nova_hip.h)."""
 
-    _fields_ = [(k, c_float) for k in ("guidance", "kx", "kv", "clip", "c0", "cx", "sigma")]
+    _fields_ = [(k, c_float) for k in ("guidance", "kx", "kv", "clip", "c0", "cx", "sigma", "extra_scale")] + [("extra_kind", c_int)]
 
 
 # name -> argtypes; every function returns int status. Must list EVERY symbol of nova_hip.h
@@ -73,6 +73,9 @@ SIGNATURES = {
     "nova_head_cfg_euler": [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_float, c_int, c_void_p],
     "nova_vit_blocks_forward": [ctypes.POINTER(VitBlock), c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_int]
     + [c_void_p] * 4 + [c_int, c_void_p],
+    "nova_vit_blocks_forward_kv": [ctypes.POINTER(VitBlock), c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_int]
+    + [c_void_p, c_long, c_long] + [c_void_p] * 4 + [c_int, c_void_p],
+    "nova_modulate_rows": [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p],
     "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]
     + [c_int] * 6 + [c_void_p] * 7 + [c_int, c_void_p],
 }

@@ -140,27 +140,32 @@ def apply_rope(x, weight):
     return w[..., 0].mul(x[..., 0]).add(w[..., 1] * x[..., 1]).flatten(3)
 
 
-def attention(p, pre, x, heads, rope=None):
-    """vision_transformer.py:51-64 Attention.forward (no KV cache, no mask)."""
+def attention(p, pre, x, heads, rope=None, cache=None):
+    """vision_transformer.py:51-64 Attention.forward (no mask). `cache`: None, or a list that holds [k, v] of the
+    earlier calls (:55-60: the new k, v are concatenated behind them along the token axis)."""
     S, L, D = x.shape
     qkv = F.linear(x, p[pre + "qkv.weight"], p[pre + "qkv.bias"])
     q, k, v = qkv.view(S, L, 3, heads, D // heads).permute(2, 0, 3, 1, 4).unbind(0)
     if rope is not None:
         q, k = apply_rope(q, rope), apply_rope(k, rope)
+    if cache is not None:
+        if cache:
+            k, v = torch.cat([cache[0], k], dim=2), torch.cat([cache[1], v], dim=2)
+        cache[:] = [k, v]
     o = F.scaled_dot_product_attention(q, k, v)
     return F.linear(o.transpose(1, 2).flatten(2), p[pre + "proj.weight"], p[pre + "proj.bias"])
 
 
-def vit_block(p, pre, x, heads, rope=None):
+def vit_block(p, pre, x, heads, rope=None, cache=None):
     """vision_transformer.py:78-92 Block.forward — POST-norm: x = LN(f(x)) + x."""
-    a = attention(p, pre + "attn.", x, heads, rope)
+    a = attention(p, pre + "attn.", x, heads, rope, cache)
     x = layer_norm(a, p[pre + "norm1.weight"], p[pre + "norm1.bias"]) + x
     m = F.linear(F.gelu(F.linear(x, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"])),
                  p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"])
     return layer_norm(m, p[pre + "norm2.weight"], p[pre + "norm2.bias"]) + x
 
 
-def vit_forward(p, pre, depth, heads, x, c=None, prev_ids=None, pos=None, pos_embed=None):
+def vit_forward(p, pre, depth, heads, x, c=None, prev_ids=None, pos=None, pos_embed=None, caches=None):
     """vision_transformer.py:128-146 VisionTransformer.forward for token input x [S,N,D].
 
     The MAE-style split: blocks[:depth/2] see [c ; known tokens], blocks[depth/2:] see
@@ -180,14 +185,14 @@ def vit_forward(p, pre, depth, heads, x, c=None, prev_ids=None, pos=None, pos_em
     x = x if c is None else torch.cat([c, x], dim=1)
     enc = depth // 2
     for i in range(enc):
-        x = vit_block(p, f"{pre}blocks.{i}.", x, heads, pe1)
+        x = vit_block(p, f"{pre}blocks.{i}.", x, heads, pe1, None if caches is None else caches[i])
     if prev_ids is not None and c is not None:
         c, x = x.split((c.size(1), x.size(1) - c.size(1)), dim=1)
     if prev_ids is not None:
         x = x_masked.scatter(1, prev_ids.expand(-1, -1, x.size(-1)), x)
         x = x if c is None else torch.cat([c, x], dim=1)
     for i in range(enc, depth):
-        x = vit_block(p, f"{pre}blocks.{i}.", x, heads, pe2)
+        x = vit_block(p, f"{pre}blocks.{i}.", x, heads, pe2, None if caches is None else caches[i])
     x = x if c is None else x[:, c.size(1):]
     return layer_norm(x, p[pre + "norm.weight"], p[pre + "norm.bias"])
 
@@ -269,6 +274,29 @@ def video_time_embed(p, pre, t, base_t):
     return layer_norm(h, p[pre + "norm.weight"], p[pre + "norm.bias"])
 
 
+def motion_embed(p, pre, rows, flow=None, fps=None, base_flow=5, base_fps=12):
+    """embeddings.py:119-137 MotionEmbed.forward: two tokens per row, [rows, 2, D] (flow token then fps token)."""
+    freq_m = 1 / (10000 ** (torch.arange(128, dtype=torch.float32).unsqueeze(0) / 128))
+    out = []
+    for k, vals, base in (("flow", flow, base_flow), ("fps", fps, base_fps)):
+        vals = [base] * rows if vals is None else vals
+        f = torch.as_tensor(vals).view(-1, 1, 1).float().mul(freq_m)
+        sincos = torch.cat([f.sin(), f.cos()], dim=-1).to(p[f"{pre}{k}_proj.0.weight"].dtype)
+        out.append(F.linear(F.silu(F.linear(sincos, p[f"{pre}{k}_proj.0.weight"], p[f"{pre}{k}_proj.0.bias"])),
+                            p[f"{pre}{k}_proj.2.weight"], p[f"{pre}{k}_proj.2.bias"]))
+    return torch.cat(out, dim=1)
+
+
+def frame_mixer(p, pre, x, z):
+    """normalization.py:33-36,41-46 AdaLayerNorm(dim, rank, eps=None).forward(x, z) as assembled at transformer_nova.py:87-89:
+    no normalisation, x * (1 + scale) + shift with (scale, shift) = proj(lora(SiLU(z)))."""
+    h = F.silu(z)
+    if pre + "lora.weight" in p:
+        h = F.linear(h, p[pre + "lora.weight"])
+    scale, shift = F.linear(h, p[pre + "proj.weight"], p[pre + "proj.bias"]).chunk(2, dim=-1)
+    return x * (1 + scale) + shift
+
+
 # ----------------------------------------------------------------------------------------------
 # the generation loop
 # ----------------------------------------------------------------------------------------------
@@ -289,102 +317,153 @@ def make_config(image_dim, latent_hw, patch, embed_dim, heads, video_depth, imag
 
 def generate(p, cfg, prompt, num_preds, num_diffusion_steps=25, guidance_scale=5.0, generator=None,
              shift=1.0, dtype=torch.float32, u_dist=None, noises=None, trace=None, guidance_trunc=0, guidance_renorm=1,
-             ddpm=None):
-    """Transformer3DModel.forward in eval mode for T = 1 (transformer_3d.py:63-77,102-164,192-200).
+             ddpm=None, max_latent_length=1, image_guidance_scale=0, spatiotemporal_guidance_scale=0, motion_flow=None,
+             fps=None, latents=None):
+    """Transformer3DModel.forward in eval mode (transformer_3d.py:63-77,102-164,192-200).
 
-    prompt: [2B, Lt, token_dim] from encode_prompt_embeds. Returns x [B, C, 1, H, W].
-    RNG contract: one uniform_ [B,N,1] (embeddings.py:265) then one normal_ [B,C,H,W] per AR step
-    (transformer_3d.py:131), all from `generator`; `u_dist` / `noises` replay pre-drawn values
-    instead (used to compare dtypes / devices on identical noise). `trace` (dict) collects
-    intermediates for the tests.
+    prompt: [2B, Lt, token_dim] from encode_prompt_embeds ([B, ...] when guidance_scale <= 1). Returns x [B, C, T, H, W]
+    with T = max_latent_length (a point set is T = 1).
+    RNG contract: one uniform_ [B,N,1] (embeddings.py:265) then one normal_ [B,C,H,W] per AR step of every generated
+    frame (transformer_3d.py:131), all from `generator`; `u_dist` / `noises` replay pre-drawn values instead (used to
+    compare dtypes / devices on identical noise). `trace` (dict) collects intermediates for the tests.
+    T > 1: KV-cached conditioning encoder (vision_transformer.py:55-60), frame positions (transformer_3d.py:143-150),
+    frame mixer when the weights hold `video_encoder.mixer.*` (:156-158), `latents` = [first frame] given (:159-160).
+    motion_flow (list, one value per sample): MotionEmbed tokens appended to the text prefix when the weights hold
+    `motion_embed.*` (:72-75). image / spatiotemporal guidance: the 3-pass forms of guidance_scaler.py:37-57,78-85.
     """
     p = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in p.items()}
     D, heads, C, patch = cfg.embed_dim, cfg.heads, cfg.image_dim, cfg.patch
     (H, W), (h, w), (hv, wv) = cfg.latent_hw, cfg.image_hw, cfg.video_hw
-    N, Nv = h * w, hv * wv
-    S = prompt.shape[0]
+    N, Nv, T = h * w, hv * wv, max_latent_length
     cfg_on = guidance_scale > 1
-    B = S // 2 if cfg_on else S
-    expand = (lambda t: torch.cat([t, t])) if cfg_on else (lambda t: t)
+    extra_pass = image_guidance_scale + spatiotemporal_guidance_scale > 0
+    passes = (3 if extra_pass else 2) if cfg_on else 1
+    B = prompt.shape[0] // 2 if cfg_on else prompt.shape[0]
+    expand = (lambda t: torch.cat([t] * passes)) if cfg_on else (lambda t: t)
 
-    # preprocess :63-77 — TextEmbed.forward embeddings.py:203-206
+    # preprocess :63-77 — TextEmbed.forward embeddings.py:203-206 (+ MotionEmbed :72-75)
     c_txt = layer_norm(F.linear(prompt.to(dtype), p["text_embed.proj.weight"], p["text_embed.proj.bias"]),
                        p["text_embed.norm.weight"], p["text_embed.norm.bias"])
+    if motion_flow is not None and "motion_embed.flow_proj.0.weight" in p:
+        flow = list(motion_flow) * (2 if cfg_on else 1)
+        fps_rows = list(fps) * (2 if cfg_on else 1) if fps else None
+        c_txt = torch.cat([c_txt, motion_embed(p, "motion_embed.", c_txt.shape[0], flow, fps_rows).to(dtype)], dim=1)
+    if passes == 3:  # expand_text guidance_scaler.py:46-51: [cond, uncond] + [uncond] (image) or + [cond] (spatiotemporal)
+        cond_rows, uncond_rows = c_txt.chunk(2)
+        c_txt = torch.cat([cond_rows, uncond_rows, uncond_rows if image_guidance_scale else cond_rows])
+    S = c_txt.shape[0]
     timesteps, sigmas = cfm_sigmas(num_diffusion_steps, shift)
     ddpm_steps = ddpm_plan(num_diffusion_steps, **ddpm) if ddpm is not None else None
     if ddpm_steps is not None:
         timesteps = [np.int64(st[0]) for st in ddpm_steps]
 
-    # generate_video :135-164, t = 0 only
+    # generate_video :135-164
     bos, mask_token = p["mask_embed.bos_token"], p["mask_embed.mask_token"]
-    cv = bos.expand(B, Nv, D).clone()  # :152-153 patch_embed output overwritten by bos_token
-    if cfg.rotary:
-        pos_v = rope_pos(1, 1, cfg.video_hw)
-        img_pe = None
-    else:
-        cv = cv + video_time_embed(p, "video_pos_embed.", 1, cfg.video_base_t)[0]  # :154 add_(time_embed[t])
-        cv = cv + sincos_2d(D, hv, wv).to(dtype)  # VideoPosEmbed.forward embeddings.py:113-115
-        pos_v = None
-        img_pe = sincos_2d(D, h, w).to(dtype)
-    cv = expand(cv)
-    c = vit_forward(p, "video_encoder.", cfg.video_depth, heads, cv, c_txt, None, pos_v)
-    if trace is not None:
-        trace["c"] = c.clone()
-
-    # generate_frame :115-133
+    img_pe = None if cfg.rotary else sincos_2d(D, h, w).to(dtype)
+    time_pos = rope_pos(T, 1, cfg.video_hw).chunk(T, 1) if cfg.rotary else None
+    time_embed = None if cfg.rotary else video_time_embed(p, "video_pos_embed.", T, cfg.video_base_t)
+    caches = [[] for _ in range(cfg.video_depth)] if T > 1 else None
+    mixing = "video_encoder.mixer.proj.weight" in p
     x = torch.zeros(B, C, H, W, dtype=dtype)
     noise = torch.empty(B, C, H, W, dtype=dtype)
-    mask = torch.ones(B, N, 1, dtype=dtype)
     pos = rope_pos(1, S, cfg.image_hw) if cfg.rotary else None
-    if u_dist is None:
-        u_dist = torch.empty_like(mask).uniform_(generator=generator)
-    order = u_dist.argsort(dim=1)  # embeddings.py:265-266
+    order = None
+    latents = list(latents) if latents else []
+    given = bool(latents)
+    c_first = None
+    step_no = 0
     if trace is not None:
-        trace["order"] = order.clone()
-        trace["z"] = []
-    pred_pos, prev_ids = 0, None
-    for i, n in enumerate([int(v) for v in num_preds if v > 0]):
-        z = patch_embed(p, "image_encoder.patch_embed.", x, patch)
-        z = z * (1 - mask) + mask_token * mask  # embeddings.py:272-274 with the mask BEFORE this step's update
-        pred_ids = order[:, pred_pos:pred_pos + n]
-        pred_mask = torch.zeros_like(mask).scatter_(1, pred_ids, 1)
-        pred_pos, mask = pred_pos + n, mask * (1 - pred_mask)
-        pred_ids = expand(pred_ids)
-        prev_ids = prev_ids if i else pred_ids.new_empty((pred_ids.size(0), 0, 1))
-        z = vit_forward(p, "image_encoder.", cfg.image_depth, heads, expand(z), c, prev_ids, pos, img_pe)
+        trace["z"], trace["c_frames"] = [], []
+    for t in range(T):
+        cv = patch_embed(p, "video_encoder.patch_embed.", x, cfg.video_patch)  # :151 (patch 2p conv of the previous frame)
+        if t == 0:
+            cv = bos.expand(B, Nv, D).clone()  # :152 overwritten by bos_token
+        if not cfg.rotary:
+            cv = cv + time_embed[t]  # :153 add_(time_embed[t])
+            cv = cv + sincos_2d(D, hv, wv).to(dtype)  # VideoPosEmbed.forward embeddings.py:113-115
+        if cfg_on:  # expand(c, padding=bos) guidance_scaler.py:39-44
+            cv = torch.stack([cv] * passes)
+            if image_guidance_scale:
+                cv[1] = bos
+            cv = cv.flatten(0, 1)
+        c = vit_forward(p, "video_encoder.", cfg.video_depth, heads, cv, None if t else c_txt, None,
+                        time_pos[t] if cfg.rotary else None, caches=caches)
         if trace is not None:
-            trace["z"].append(z.clone())
-        prev_ids = torch.cat([prev_ids, pred_ids], dim=1)
-        if noises is None:
-            noise.normal_(generator=generator)
-        else:
-            noise = noises[i].to(dtype)
-        # denoise :102-113 (2-pass CFG; guidance_trunc / guidance_renorm per guidance_scaler.py:59-72)
-        xt = noise
-        zz, ids, cfg_live = z, pred_ids, cfg_on
-        for j, t in enumerate(timesteps):
-            if cfg_live and guidance_trunc and float(t) < guidance_trunc:  # maybe_disable :59-65: stays off afterwards
-                cfg_live, zz, ids = False, zz.chunk(2)[0], ids.chunk(2)[0]
-            timestep = torch.as_tensor(t).expand(zz.shape[0])
-            x_in = expand(xt) if cfg_live else xt
-            pred = diffusion_mlp(p, "image_decoder.", cfg.decoder_depth, x_in, timestep, zz, ids, patch)
-            if cfg_live:  # scale :67-87
-                cond, uncond = pred.chunk(2)
-                pred = uncond + (cond - uncond) * guidance_scale
-                if guidance_renorm < 1:  # renorm :67-72, norms over every row of the sample (echo rows included)
-                    dims = tuple(range(1, pred.dim()))
-                    ratio = cond.norm(dim=dims, keepdim=True) / pred.norm(dim=dims, keepdim=True)
-                    pred = pred * ratio.clamp(guidance_renorm, 1)
-            pred = unpatchify(pred, patch, C, h, w)
-            if ddpm_steps is None:
-                dt = sigmas[j + 1] - sigmas[j]  # scheduling_cfm.py:134-135
-                xt = pred * dt + xt
-            else:  # scheduling_ddpm.py:268-312
-                _, kx, kv, c0, cx, sigma = ddpm_steps[j]
-                x0 = kx * xt + kv * pred
-                xt = c0 * x0 + cx * xt
-                if int(t) > 0:
-                    xt = xt + sigma * torch.randn(xt.shape, generator=generator, dtype=dtype)
-        sample = patchify(xt, patch)
-        x = x + unpatchify(sample * pred_mask, patch, C, h, w)  # :133
-    return x.unsqueeze(2)
+            trace["c"] = c.clone()
+            trace["c_frames"].append(c.clone())
+        if mixing:  # :156-158
+            c_first = c if t == 0 else c_first
+            c = frame_mixer(p, "video_encoder.mixer.", c_first, c) if t else c
+        if t == 0 and given:  # :159-160
+            x = latents[-1].to(dtype).clone()
+            continue
+
+        # generate_frame :115-133
+        x = torch.zeros(B, C, H, W, dtype=dtype)
+        mask = torch.ones(B, N, 1, dtype=dtype)
+        if order is None:
+            if u_dist is None:
+                u_dist = torch.empty_like(mask).uniform_(generator=generator)
+            order = u_dist.argsort(dim=1)  # embeddings.py:265-266
+            if trace is not None:
+                trace["order"] = order.clone()
+        pred_pos, prev_ids = 0, None
+        sched = [int(v) for v in num_preds if v > 0]
+        for i, n in enumerate(sched):
+            g_now = guidance_scale  # decay_guidance_scale with min_guidance_scale = None: constant (:31-35)
+            z = patch_embed(p, "image_encoder.patch_embed.", x, patch)
+            z = z * (1 - mask) + mask_token * mask  # embeddings.py:272-274 with the mask BEFORE this step's update
+            pred_ids = order[:, pred_pos:pred_pos + n]
+            pred_mask = torch.zeros_like(mask).scatter_(1, pred_ids, 1)
+            pred_pos, mask = pred_pos + n, mask * (1 - pred_mask)
+            pred_ids = expand(pred_ids)
+            prev_ids = prev_ids if i else pred_ids.new_empty((pred_ids.size(0), 0, 1))
+            z = vit_forward(p, "image_encoder.", cfg.image_depth, heads, expand(z), c, prev_ids, pos, img_pe)
+            if trace is not None:
+                trace["z"].append(z.clone())
+            prev_ids = torch.cat([prev_ids, pred_ids], dim=1)
+            if noises is None:
+                noise.normal_(generator=generator)
+            else:
+                noise = noises[step_no].to(dtype)
+            step_no += 1
+            # denoise :102-113 (guidance passes; guidance_trunc / guidance_renorm per guidance_scaler.py:59-72)
+            xt = noise
+            zz, ids, cfg_live = z, pred_ids, cfg_on
+            for j, tt in enumerate(timesteps):
+                if cfg_live and guidance_trunc and float(tt) < guidance_trunc:  # maybe_disable :59-65: stays off afterwards
+                    cfg_live, zz, ids = False, zz.chunk(passes)[0], ids.chunk(passes)[0]
+                timestep = torch.as_tensor(tt).expand(zz.shape[0])
+                x_in = expand(xt) if cfg_live else xt
+                pred = diffusion_mlp(p, "image_decoder.", cfg.decoder_depth, x_in, timestep, zz, ids, patch)
+                if cfg_live:  # scale :74-87
+                    def renorm(v, cond):  # :67-72, norms over every row of the sample (echo rows included)
+                        if guidance_renorm >= 1:
+                            return v
+                        dims = tuple(range(1, v.dim()))
+                        ratio = cond.norm(dim=dims, keepdim=True) / v.norm(dim=dims, keepdim=True)
+                        return v * ratio.clamp(guidance_renorm, 1)
+
+                    if image_guidance_scale:  # :78-81
+                        cond, uncond, imgcond = pred.chunk(3)
+                        pred = renorm(uncond + (cond - imgcond) * g_now, cond) + (imgcond - uncond) * image_guidance_scale
+                    elif spatiotemporal_guidance_scale:  # :82-85
+                        cond, uncond, perturb = pred.chunk(3)
+                        pred = renorm(uncond + (cond - uncond) * g_now, cond) + (cond - perturb) * spatiotemporal_guidance_scale
+                    else:  # :86-87
+                        cond, uncond = pred.chunk(2)
+                        pred = renorm(uncond + (cond - uncond) * g_now, cond)
+                pred = unpatchify(pred, patch, C, h, w)
+                if ddpm_steps is None:
+                    dt = sigmas[j + 1] - sigmas[j]  # scheduling_cfm.py:134-135
+                    xt = pred * dt + xt
+                else:  # scheduling_ddpm.py:268-312
+                    _, kx, kv, c0, cx, sigma = ddpm_steps[j]
+                    x0 = kx * xt + kv * pred
+                    xt = c0 * x0 + cx * xt
+                    if int(tt) > 0:
+                        xt = xt + sigma * torch.randn(xt.shape, generator=generator, dtype=dtype)
+            sample = patchify(xt, patch)
+            x = x + unpatchify(sample * pred_mask, patch, C, h, w)  # :133
+        latents.append(x.clone())
+    return torch.stack(latents, dim=2)

@@ -6,6 +6,7 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["tiny_rope", "tiny_abspe"]
+VIDEO_CASES = ["tiny_video_rope", "tiny_video_abspe"]  # tests/golden/make_golden_video.py: T > 1, mixer, motion tokens, 3-pass guidance
 
 
 def bf16_bits_to_f32(a):
@@ -27,4 +28,5 @@ class Golden(object):
 
         m = self.meta
         return O.make_config(m["image_dim"], (m["latent_h"], m["latent_w"]), m["patch"], m["D"], m["heads"],
-                             m["video_depth"], m["image_depth"], m["decoder_depth"], m["token_len"], bool(m["rotary"]))
+                             m["video_depth"], m["image_depth"], m["decoder_depth"], m["token_len"], bool(m["rotary"]),
+                             video_base_t=m.get("T", 1))

@@ -36,7 +36,7 @@ def test_ctypes_table_matches_header(built_lib):
     table = set(built_lib.SIGNATURES) | set(built_lib.PLAIN)
     assert table == declared_symbols(), sorted(table ^ declared_symbols())
     lib = built_lib.load(check_device=False)   # binds every symbol; no compute without a GPU
-    assert lib.nova_version() == 100
+    assert lib.nova_version() == int(re.search(r"#define NOVA_HIP_VERSION (\d+)", open(HEADER).read()).group(1))
 
 
 def test_every_entry_point_cites_the_reference():

@@ -10,7 +10,7 @@ import sys
 import pytest
 import torch
 
-from golden_util import CASES, Golden
+from golden_util import CASES, VIDEO_CASES, Golden
 from oracle import nova_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -21,7 +21,7 @@ if PKG not in sys.path:
 
 from diffnext.pipelines import NOVAPipeline  # noqa: E402
 from diffnext.schedulers import FlowMatchEulerDiscreteScheduler  # noqa: E402
-from test_mirror_cpu import build_from_golden  # noqa: E402
+from test_mirror_cpu import VIDEO_VARIANTS, build_from_golden, video_call  # noqa: E402
 
 
 def rel(a, b):
@@ -376,3 +376,46 @@ def test_training_step_on_gpu_takes_the_torch_path_and_matches_cpu(gold, hip):
     for k in g_cpu:
         scale = g_cpu[k].abs().max()
         assert (g_gpu[k] - g_cpu[k]).abs().max() <= 5e-3 * scale + 1e-7, k
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-frame generation (KV-cached conditioning encoder, frame mixer, motion tokens,
+# prefilled first frame) and 3-pass guidance on the HIP path, against runs of the reference's own generate_video
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module", params=VIDEO_CASES)
+def vgold(request):
+    return Golden(request.param)
+
+
+@pytest.mark.parametrize("key,kw", VIDEO_VARIANTS)
+def test_multi_frame_and_three_pass_f32_match_reference(vgold, hip, key, kw):
+    _, x = video_call(vgold, "cuda", torch.float32, **kw)
+    ref = vgold.t[key]
+    assert x.is_cuda and x.shape == ref.shape
+    err = rel(x, ref)
+    assert err < 1e-4, (key, err)
+
+
+def test_prefilled_first_frame_f32_matches_reference(vgold, hip):
+    first = vgold.t["out/x"][:, :, 0].clone()
+    _, x = video_call(vgold, "cuda", torch.float32, latents=[first.cuda()])
+    ref = vgold.t["out/x_prefilled"]
+    assert torch.equal(x[:, :, 0].cpu(), first)
+    assert rel(x, ref) < 1e-4
+
+
+def test_multi_frame_bf16_and_lanes(vgold, hip):
+    """Throughput mode with the recorded order / per-step noise injected (rms-relative), and lanes = 2 == lanes = 1."""
+    order, noises = vgold.t["out/order"][..., 0], vgold.t["in/noises"]
+    kw = dict(pred_order=order, noise_fn=lambda i: noises[i], generator=None)
+    _, x = video_call(vgold, "cuda", torch.bfloat16, **kw)
+    assert rms_rel(x.float(), vgold.t["out/x"]) < 6e-2
+    if vgold.meta["B"] >= 2:
+        a = video_call(vgold, "cuda", torch.float32, lanes=1, **kw)[1]
+        b = video_call(vgold, "cuda", torch.float32, lanes=2, **kw)[1]
+        assert torch.equal(a, b)
+
+
+def test_three_pass_rejects_both_scales(vgold, hip):
+    with pytest.raises(ValueError):
+        video_call(vgold, "cuda", torch.float32, image_guidance_scale=1.0, spatiotemporal_guidance_scale=1.0)

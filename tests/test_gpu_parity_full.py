@@ -41,9 +41,10 @@ def rms_rel(a, b):
 
 # (width, heads, latent H, W, batch, AR steps, diffusion steps, bf16 rms-rel bound)
 ARCHS = {
-    "d48w1024_2048pts": (1024, 16, 32, 64, 2, 3, 2, 6e-2),  # configs[2] / [3]: the headline architecture
-    "d48w768_1024pts": (768, 12, 32, 32, 2, 3, 2, 6e-2),    # configs[1]
-    "d48w1536_2048pts": (1536, 16, 32, 64, 1, 2, 2, 6e-2),  # configs[4] architecture (head_dim 96) in f32 / bf16
+    # measured on MI355X (profiles/r02_parity_full.log): f32 3.5e-5 / 1.7e-5 / 2.2e-5 max-rel; bf16 2.1e-2 / 1.8e-2 / 1.9e-2 rms-rel
+    "d48w1024_2048pts": (1024, 16, 32, 64, 2, 3, 2, 4e-2),  # configs[2] / [3]: the headline architecture
+    "d48w768_1024pts": (768, 12, 32, 32, 2, 3, 2, 4e-2),    # configs[1]
+    "d48w1536_2048pts": (1536, 16, 32, 64, 1, 2, 2, 4e-2),  # configs[4] architecture (head_dim 96) in f32 / bf16
 }
 
 
@@ -97,6 +98,7 @@ def test_f32_from_seed_matches_oracle_at_full_depth(case, hip):
     err, rms = rel(x, case["ref"]), rms_rel(x, case["ref"])
     print(f"\n[parity-full] {case['name']} f32 from seed: max rel {err:.3e}, rms rel {rms:.3e}")
     assert err < 1e-3, err
+    assert err < 2e-4, f"f32 MFMA path measured 2-4e-5 at full depth, got {err:.3e}"
 
 
 def test_bf16_injected_draws_close_to_oracle_at_full_depth(case, hip):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, Golden
+from golden_util import CASES, VIDEO_CASES, Golden
 
 PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nova_pointcloud_amd")
 if PKG not in sys.path:
@@ -32,8 +32,8 @@ def build_from_golden(g, dtype=torch.float32, device="cpu"):
     base = [H // m["patch"], W // m["patch"]]
     model = TN.NOVATransformer3DModel(
         image_dim=m["image_dim"], image_size=(H * stride, W * stride), image_stride=stride, text_token_dim=m["token_dim"],
-        text_token_len=m["token_len"], image_base_size=base, video_base_size=[1, base[0] // 2, base[1] // 2],
-        rotary_pos_embed=bool(m["rotary"]),
+        text_token_len=m["token_len"], image_base_size=base, video_base_size=[m.get("T", 1), base[0] // 2, base[1] // 2],
+        video_mixer_rank=None if m.get("mixer_rank", -999) == -999 else m["mixer_rank"], rotary_pos_embed=bool(m["rotary"]),
         arch=(f"vit_d{m['video_depth']}w{D}", f"vit_d{m['image_depth']}w{D}", f"mlp_d{m['decoder_depth']}w{D}"))
     missing = model.load_state_dict(g.weights, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
@@ -66,6 +66,44 @@ def test_pipeline_cpu_matches_reference(gold):
     assert torch.equal(pipe.transformer.mask_embed.pred_ids, gold.t["out/order"])
     pts = points_from_latents(x)
     assert pts.shape == (m["B"], m["latent_h"] * m["latent_w"], 3)
+
+
+@pytest.fixture(scope="module", params=VIDEO_CASES)
+def vgold(request):
+    return Golden(request.param)
+
+
+def video_call(vgold, device="cpu", dtype=torch.float32, **kw):
+    m = vgold.meta
+    pipe = NOVAPipeline(transformer=build_from_golden(vgold, dtype, device), scheduler=FlowMatchEulerDiscreteScheduler())
+    args = dict(prompt_embeds=[p.to(device) for p in vgold.prompt_embeds], num_inference_steps=m["K"], num_diffusion_steps=m["S"],
+                max_latent_length=m["T"], guidance_scale=m["guidance"], motion_flow=m["flow"],
+                generator=torch.Generator().manual_seed(m["sample_seed"]), output_type="latent", disable_progress_bar=True)
+    args.update(kw)
+    return pipe, pipe(**args).frames
+
+
+VIDEO_VARIANTS = [("out/x", {}), ("out/x_image_guidance", dict(image_guidance_scale=1.5)),
+                  ("out/x_spatiotemporal_guidance", dict(spatiotemporal_guidance_scale=0.75)),
+                  ("out/x_image_guidance_renorm", dict(image_guidance_scale=1.5, guidance_renorm=0.4, guidance_trunc=300.0))]
+
+
+@pytest.mark.parametrize("key,kw", VIDEO_VARIANTS)
+def test_multi_frame_pipeline_cpu_matches_reference(vgold, key, kw):
+    """max_latent_length > 1 (KV-cached conditioning encoder, frame mixer, motion tokens) and the 3-pass guidance forms,
+    module path on CPU against the reference's generate_video runs."""
+    pipe, x = video_call(vgold, **kw)
+    ref = vgold.t[key]
+    assert x.shape == ref.shape
+    assert (x - ref).abs().max() <= 2e-5 * ref.abs().max()
+    sd = pipe.transformer.state_dict()
+    assert set(sd) == set(vgold.weights)
+
+
+def test_prefilled_first_frame_cpu_matches_reference(vgold):
+    _, x = video_call(vgold, latents=[vgold.t["out/x"][:, :, 0].clone()])
+    ref = vgold.t["out/x_prefilled"]
+    assert (x - ref).abs().max() <= 2e-5 * ref.abs().max()
 
 
 def test_call_signature_matches_reference():

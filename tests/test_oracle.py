@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import CASES, Golden
+from golden_util import CASES, VIDEO_CASES, Golden
 from oracle import nova_oracle as O
 
 
@@ -97,3 +97,51 @@ def test_ddpm_plan_basics():
     assert plan[-1][5] == 0.0 and all(p[5] > 0 for p in plan[:-1])  # no noise at t = 0
     t, kx, kv, c0, cx, sigma = plan[-1]
     assert abs(cx) < 1e-6 and abs(c0 - 1.0) < 1e-6  # last step returns the predicted x0
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-frame generation (KV-cached conditioning encoder, frame mixer, motion tokens) and 3-pass guidance:
+# the oracle against runs of the reference's own generate_video (tests/golden/make_golden_video.py)
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module", params=VIDEO_CASES)
+def vgold(request):
+    return Golden(request.param)
+
+
+def _vrun(vgold, **kw):
+    m = vgold.meta
+    args = dict(num_diffusion_steps=m["S"], guidance_scale=m["guidance"], max_latent_length=m["T"], motion_flow=[m["flow"]] * m["B"],
+                generator=torch.Generator().manual_seed(m["sample_seed"]))
+    args.update(kw)
+    return O.generate(vgold.weights, vgold.oracle_config(), vgold.t["in/prompt"], vgold.t["in/num_preds"].numpy(), **args)
+
+
+def test_video_generate_matches_reference(vgold):
+    trace = {}
+    x = _vrun(vgold, trace=trace)
+    ref = vgold.t["out/x"]
+    assert x.shape == ref.shape and x.shape[2] == vgold.meta["T"]
+    assert torch.equal(trace["order"], vgold.t["out/order"])
+    cf = torch.stack(trace["c_frames"])
+    assert (cf - vgold.t["out/c_frames"]).abs().max() <= 2e-5 * vgold.t["out/c_frames"].abs().max()
+    assert (x - ref).abs().max() <= 2e-5 * ref.abs().max()
+    # replaying the recorded draws gives the same frames (RNG contract: one uniform, one normal per AR step per frame)
+    y = _vrun(vgold, generator=None, u_dist=vgold.t["in/u_dist"], noises=list(vgold.t["in/noises"]))
+    assert (y - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
+@pytest.mark.parametrize("key,kw", [("out/x_image_guidance", dict(image_guidance_scale=1.5)),
+                                    ("out/x_spatiotemporal_guidance", dict(spatiotemporal_guidance_scale=0.75)),
+                                    ("out/x_image_guidance_renorm", dict(image_guidance_scale=1.5, guidance_renorm=0.4, guidance_trunc=300.0))])
+def test_three_pass_guidance_matches_reference(vgold, key, kw):
+    x = _vrun(vgold, **kw)
+    ref = vgold.t[key]
+    assert (x - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
+def test_prefilled_first_frame_matches_reference(vgold):
+    first = vgold.t["out/x"][:, :, 0]
+    x = _vrun(vgold, latents=[first])
+    ref = vgold.t["out/x_prefilled"]
+    assert x.shape == ref.shape and torch.equal(x[:, :, 0], first)
+    assert (x - ref).abs().max() <= 2e-5 * ref.abs().max()
