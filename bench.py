@@ -110,6 +110,38 @@ def cpu_baseline(pipe, width, heads, H, W, threads):
                       f"({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {tflops:.3f} TFLOP/s), scaled by FLOPs to 64x25"}
 
 
+PMC_KERNEL = {"attention": "attn_bf16<64>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
+              "qkv_gemm_rope": "gemm256p_kernel<bf16,3>"}
+
+
+def pmc_traffic(family, workload):
+    """HBM bytes per launch of the dominant kernel from the newest profiles/r*_pmc.json (tools/pmc_collect.sh +
+    tools/pmc_summary.py: separate rocprofv3 --pmc passes; counters cannot be read from inside the process). The file
+    records the sha256 of the kernel sources it was measured on: a stale file is reported as such, not used."""
+    import glob
+    import hashlib
+
+    if workload != "d48w1024_2048pts_b32":
+        return None, "PMC passes are taken at the d48w1024 shapes only"
+    h = hashlib.sha256()
+    csrc = os.path.join(PKG, "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+            rec = doc["kernels"][PMC_KERNEL[family]]
+        except (OSError, KeyError, ValueError):
+            continue
+        name = os.path.basename(path)
+        if doc.get("source_sha256") != h.hexdigest():
+            return None, f"profiles/{name} was measured on other kernel sources (sha mismatch): re-run tools/pmc_collect.sh"
+        return rec.get("hbm_bytes"), (f"profiles/{name}: {doc['shape']}; 2 x FETCH_SIZE + WRITE_SIZE of the {PMC_KERNEL[family]} launch, "
+                                      f"separate rocprofv3 --pmc passes")
+    return None, "no profiles/r*_pmc.json"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,15 +255,7 @@ def main():
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read from inside
         # the process); the committed summary is for the largest launch of that kernel, so it is reported with its context.
-        traffic, traffic_note = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))[dom]
-            if args.workload == "d48w1024_2048pts_b32":
-                traffic = pmc["hbm_bytes_per_launch"]
-                traffic_note = (f"PMC bytes of the {pmc['launch']} launch ({pmc['source']}); algorithmic bytes of that launch "
-                                f"{pmc['algorithmic_bytes_per_launch'] / 1e6:.1f} MB")
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_note = pmc_traffic(dom, args.workload)
         rec = {
             "metric": "generated points/sec/node, NOVA-d48w1024 @2048 pts, 64-step sample" if args.workload.startswith("d48w1024")
             else f"generated points/sec/node, {args.workload}",

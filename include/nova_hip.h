@@ -56,7 +56,8 @@ int nova_prof_enable(int on);
 int nova_prof_collect(double* ms, double* work, long long* launches, int slots);
 
 /* Test hook: 0 = automatic choice between the 128x128 and the 256x256 (large-M) GEMM structures,
- * 128 / 256 = force one (both compute bit-identical results; tests/test_gpu_kernels.py compares them). */
+ * 128 / 256 = force one, 257 = the 256 structure in its one-tile-per-workgroup form (the fallback of the persistent
+ * kernel); all compute bit-identical results (tests/test_gpu_kernels.py compares them). */
 int nova_debug_force_gemm_tile(int tile);
 
 /* ---- projection GEMM -----------------------------------------------------------------------
@@ -148,6 +149,22 @@ int nova_patch_embed_rows(const float* x, const void* w, const float* bias, void
  * (cond rows then uncond rows) when cfg != 0, [B*n, D] otherwise. */
 int nova_head_cfg_euler(const void* h, const void* w, const float* bias, float* x, int B, int n, int P, int D,
                         float guidance, int cfg, float dt, int dtype, void* stream);
+
+/* ---- point-set metrics (the step after generation) ------------------------------------------
+ * x [B, N, 3], y [B, M, 3] float32 point sets (NOVAPipeline's latent output flattened to points). Coordinates are clamped to
+ * [clamp_lo, clamp_hi] first, as the reference does before torch.cdist (test_optimize.py:357-358,388-389: +-5;
+ * train_newloss.py:321-322,357-358: +-1 / +-2).
+ *   nova_pointset_nn_dist        d[b, i] = min_j ||x[b, i] - y[b, j]||  (Euclidean, not squared): the `dist.min(dim=2)`
+ *                                of compute_chamfer_distance (test_optimize.py:367-369); call it twice, operands swapped, for
+ *                                the two directions. unit_norm != 0 scales every point to unit length after the clamp
+ *                                (distChamfer, train_newloss.py:325-337).
+ *   nova_pointset_pairwise_dist  D[b, i, j] = ||x[b, i] - y[b, j]||: the cost matrix `torch.cdist(pred[i], target[i])`
+ *                                handed to scipy's linear_sum_assignment by compute_emd_distance (test_optimize.py:399-404)
+ *                                and emd_approx (train_newloss.py:360-370). */
+int nova_pointset_nn_dist(const float* x, const float* y, float* d, int B, int N, int M, float clamp_lo, float clamp_hi,
+                          int unit_norm, void* stream);
+int nova_pointset_pairwise_dist(const float* x, const float* y, float* D, int B, int N, int M, float clamp_lo, float clamp_hi,
+                                void* stream);
 
 /* ---- composite entry points (what the AR loop actually calls) --------------------------------
  * One ViT block's parameters (reference state_dict names in comments). GEMM weights in `dtype`,

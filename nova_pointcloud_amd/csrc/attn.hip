@@ -139,6 +139,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
     const char* tv32 = tk32 + A_T32;
 
     // ---- S^T[key][q] - m for the two 32-key blocks
+    // (A/B'd in round 2, bit-identical and time-neutral: chain heads as inline asm with an early-clobber result, which
+    // removes the 8 v_mov_b64 copies of the -m block the register allocator inserts for one chain, and a written-out
+    // v_max3 chain without the canonicalising v_max - the loop is not bound by the count of such cheap instructions.)
     f16v st[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {

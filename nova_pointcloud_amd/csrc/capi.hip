@@ -107,7 +107,7 @@ int nova_check_device(void) {
 
 int nova_debug_force_gemm_tile(int tile) {
   NOVA_REQUIRE(gemm_force_tile(tile) == 0, NOVA_ERR_ARG,
-               "force_gemm_tile: this build knows 0 (auto), 128 and 256 (experiment codes need the NOVA_EXPERIMENTS build)");
+               "force_gemm_tile: this build knows 0 (auto), 128, 256 (persistent) and 257 (one tile per workgroup); experiment codes need the NOVA_EXPERIMENTS build");
   return 0;
 }
 
@@ -313,6 +313,20 @@ int nova_vit_blocks_forward_kv(const nova_vit_block* blocks, int nblocks, void* 
                cache_len, L, cache_cap);
   return vit_blocks(blocks, nblocks, x, S, L, D, heads, hidden, rope, rope_batch, ws_qkv, ws_a, ws_b, ws_h, kv_cache, cache_cap,
                     cache_len, dtype, (hipStream_t)stream);
+}
+
+int nova_pointset_nn_dist(const float* x, const float* y, float* d, int B, int N, int M, float clamp_lo, float clamp_hi,
+                          int unit_norm, void* stream) {
+  NOVA_REQUIRE(B * (long)N == 0 || (x && y && d), NOVA_ERR_ARG, "pointset_nn_dist: null pointer");
+  NOVA_REQUIRE(clamp_lo <= clamp_hi, NOVA_ERR_ARG, "pointset_nn_dist: empty clamp range");
+  return pointset_nn_dist(x, y, d, B, N, M, clamp_lo, clamp_hi, unit_norm, (hipStream_t)stream);
+}
+
+int nova_pointset_pairwise_dist(const float* x, const float* y, float* D, int B, int N, int M, float clamp_lo, float clamp_hi,
+                                void* stream) {
+  NOVA_REQUIRE(B * (long)N * M == 0 || (x && y && D), NOVA_ERR_ARG, "pointset_pairwise_dist: null pointer");
+  NOVA_REQUIRE(clamp_lo <= clamp_hi, NOVA_ERR_ARG, "pointset_pairwise_dist: empty clamp range");
+  return pointset_pairwise_dist(x, y, D, B, N, M, clamp_lo, clamp_hi, (hipStream_t)stream);
 }
 
 int nova_modulate_rows(const void* x, const void* mod, void* out, long rows, int D, int dtype, void* stream) {

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 // gemm256.hip: 256x256 ping-pong kernel for large M
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
-                   hipStream_t st);
+                   hipStream_t st, bool one_tile_per_workgroup = false);
 
 // 0 = auto, 128 / 256 = force that tile structure (tests compare the two structures bit for bit). Thread-local like
 // the walk direction: a debugging knob of the calling host thread, not shared state.
@@ -227,8 +227,8 @@ int gemm_force_tile(int tile) {
     tile = 256;
   }
 #endif
-  if (tile != 0 && tile != 128 && tile != 256) return -1;
-  g_force_tile = tile;
+  if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return -1;
+  g_force_tile = tile;  // 257: the 256 tile in its one-tile-per-workgroup form (the fallback of the persistent kernel)
   return 0;
 }
 
@@ -240,10 +240,10 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
   if (N % BN != 0 || K % kelems != 0 || K <= 0)
     return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
   const bool can256 = N % 256 == 0 && (epi != EPI_ROPE || (e.rope_cols % 256 == 0 && e.q_cols % 256 == 0));  // rotation is decided per tile
-  if (g_force_tile == 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
-  if (can256 && (g_force_tile == 256 || (g_force_tile == 0 && M >= 4096)))
+  if (g_force_tile >= 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
+  if (can256 && (g_force_tile >= 256 || (g_force_tile == 0 && M >= 4096)))
     return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols, e.q_scale, e.q_cols,
-                          sizeof(T) == 2 ? NOVA_BF16 : NOVA_F32, st);
+                          sizeof(T) == 2 ? NOVA_BF16 : NOVA_F32, st, g_force_tile == 257);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(ntm * ntn), block(256);
   ProfScope prof(PROF_GEMM_SMALL, 2.0 * M * N * K, st);

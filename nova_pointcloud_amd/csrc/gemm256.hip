@@ -714,9 +714,9 @@ int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const fl
 
 template <typename T>
 static int launch256(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
-                     hipStream_t st) {
+                     hipStream_t st, bool single) {
   // (the persistent RoPE epilogue steps through a 16-row block assuming it crosses at most one sequence boundary)
-  if (g_var256 == 20 && !(epi == E_ROPE && e.rope && e.L < 16)) return launch256p<T>(A, W, C, M, N, K, epi, e, st);
+  if (!single && g_var256 == 20 && !(epi == E_ROPE && e.rope && e.L < 16)) return launch256p<T>(A, W, C, M, N, K, epi, e, st);
 #ifdef NOVA_EXPERIMENTS
   switch (g_var256) {
     case 1: return launch256v<T, 1>(A, W, C, M, N, K, epi, e, st);
@@ -735,9 +735,10 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
 // K % (128 / sizeof(T)) == 0, K > 0, M > 0.
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
-                   hipStream_t st) {
+                   hipStream_t st, bool one_tile_per_workgroup) {
   GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, walk_is_reverse() ? 1 : 0, nullptr, nullptr, g_stagger256};
-  return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st) : launch256<float>(A, W, C, M, N, K, epi, e, st);
+  return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st, one_tile_per_workgroup)
+                            : launch256<float>(A, W, C, M, N, K, epi, e, st, one_tile_per_workgroup);
 }
 
 }  // namespace nova

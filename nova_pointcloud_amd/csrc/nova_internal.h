@@ -88,4 +88,9 @@ int renorm_euler(float* x, const float* vhat, const float* cond, const float* ex
 int kv_append(const void* qkv, void* cache, int S, int Lq, int D, long cap, long base, int dtype, hipStream_t st);
 int modulate_rows(const void* x, const void* mod, void* out, long rows, int D, int dtype, hipStream_t st);
 
+
+// ---- pointset.hip (Chamfer / EMD distance work)
+int pointset_nn_dist(const float* x, const float* y, float* d, int B, int N, int M, float lo, float hi, int unit, hipStream_t st);
+int pointset_pairwise_dist(const float* x, const float* y, float* D, int B, int N, int M, float lo, float hi, hipStream_t st);
+
 }  // namespace nova

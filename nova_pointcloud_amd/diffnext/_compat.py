@@ -184,16 +184,27 @@ except ImportError:
 
         @classmethod
         def from_pretrained(cls, directory, torch_dtype=None, **kwargs):
+            """Load from a LOCAL pipeline directory: `model_index.json` ({component: [module, class]}, the diffusers layout
+            the reference's checkpoints use) + one sub-directory per component."""
             if not os.path.isdir(directory):
                 raise OSError(f"{directory} is not a local directory (no network access from this build)")
             with open(os.path.join(directory, cls.config_name)) as f:
                 index = json.load(f)
             comps = {}
+            optional = set(getattr(cls, "_optional_components", ()))
             for name, spec in index.items():
                 if name.startswith("_") or not isinstance(spec, list) or spec[0] is None:
                     continue
-                klass = getattr(importlib.import_module(spec[0]), spec[1])
+                comp_dir = os.path.join(directory, name)
+                try:
+                    klass = getattr(importlib.import_module(spec[0]), spec[1])
+                except (ImportError, AttributeError):
+                    # a component of a library that is not installed here (diffusers' VAE, transformers' text encoder):
+                    # optional ones are left out (the point-set path needs the transformer and the scheduler only)
+                    if name in optional:
+                        continue
+                    raise
                 args = {"torch_dtype": torch_dtype} if issubclass(klass, nn.Module) else {}
-                comps[name] = klass.from_pretrained(os.path.join(directory, name), **args)
+                comps[name] = klass.from_pretrained(comp_dir, **args)
             accepted = inspect.signature(cls.__init__).parameters
             return cls(**{k: v for k, v in comps.items() if k in accepted})

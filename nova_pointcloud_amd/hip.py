@@ -75,6 +75,8 @@ SIGNATURES = {
     + [c_void_p] * 4 + [c_int, c_void_p],
     "nova_vit_blocks_forward_kv": [ctypes.POINTER(VitBlock), c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_int]
     + [c_void_p, c_long, c_long] + [c_void_p] * 4 + [c_int, c_void_p],
+    "nova_pointset_nn_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_int, c_void_p],
+    "nova_pointset_pairwise_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_void_p],
     "nova_modulate_rows": [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p],
     "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]
     + [c_int] * 6 + [c_void_p] * 7 + [c_int, c_void_p],

@@ -42,7 +42,7 @@ def test_gemm_bias_act(hip, dtype, M, N, K, act):
     assert relerr(out, ref) < tol(dtype)
 
 
-@pytest.mark.parametrize("tile", [128, 2580])
+@pytest.mark.parametrize("tile", [128, 256])
 def test_gelu_epilogue_pointwise_accuracy(hip, force_tile, tile):
     """W = I makes the accumulator equal the bf16 input exactly, so the epilogue's GELU is seen pointwise: every bf16
     value in [-16, 16] must come out within 2.6e-5 (the fitted form's bound, csrc/common.h) plus the final bf16
@@ -267,7 +267,7 @@ def test_decoder_glue(hip, dtype):
 # ---------------------------------------------------------------------------------------------
 # the two 256x256 structures: one tile per workgroup (2560 + 2: its shipped schedule variant) and the persistent
 # one-workgroup-per-CU form (2560 + 20)
-TILE256_FORMS = [2562, 2580]
+TILE256_FORMS = [257, 256]  # one tile per workgroup (fallback form), persistent (default form)
 
 
 @pytest.fixture()

@@ -163,6 +163,53 @@ def test_save_and_load_roundtrip(gold, tmp_path):
         assert torch.equal(a, b), k
 
 
+def test_pipeline_directory_layout_and_builder(gold, tmp_path):
+    """On-disk layout (reference pipelines/builder.py:31-125): model_index.json + component
+    directories, component replacement / removal / config override through get_pipeline_path, diffusers-style index
+    entries of libraries that are not installed."""
+    import json
+
+    from diffnext.pipelines.builder import build_diffusion_scheduler, build_pipeline, get_pipeline_path
+
+    base, other = tmp_path / "base", tmp_path / "other"
+    model = build_from_golden(gold)
+    NOVAPipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler(shift=2.0)).save_pretrained(str(base))
+    index = json.load(open(base / "model_index.json"))
+    assert index["_class_name"] == "NOVAPipeline" and index["transformer"][1] == "NOVATransformer3DModel"
+    assert (base / "transformer" / "config.json").exists() and (base / "scheduler" / "scheduler_config.json").exists()
+    # a checkpoint as published: VAE / text encoder entries of libraries this box does not have
+    index.update(vae=["diffusers", "AutoencoderKL"], text_encoder=["transformers", "NoSuchTextModel"])
+    json.dump(index, open(base / "model_index.json", "w"))
+    pipe = build_pipeline(str(base), NOVAPipeline, dtype=torch.float32)
+    assert pipe.vae is None and pipe.text_encoder is None and pipe.scheduler.config.shift == 2.0
+    # replace the transformer, drop the VAE, override the transformer's config (module_dict / module_config of configs/*.yaml)
+    other_model = build_from_golden(gold)
+    with torch.no_grad():
+        other_model.mask_embed.mask_token.add_(1.0)
+    other_model.save_pretrained(str(other))
+    assert get_pipeline_path(str(base)) == str(base)
+    cfg = json.load(open(other / "config.json"))
+    path = get_pipeline_path(str(base), module_dict={"transformer": str(other), "vae": ""}, module_config={"scheduler": None})
+    idx2 = json.load(open(os.path.join(path, "model_index.json")))
+    assert "vae" not in idx2 and "transformer" in idx2
+    assert os.path.islink(os.path.join(path, "scheduler", "scheduler_config.json"))
+    loaded = NOVAPipeline.from_pretrained(path)
+    assert torch.equal(loaded.transformer.mask_embed.mask_token, model.mask_embed.mask_token)  # base dir was linked first
+    path2 = get_pipeline_path(str(other.parent / "other_as_pipe") if False else str(base), module_config={"transformer": cfg},
+                              target_path=str(tmp_path / "t2"))
+    assert json.load(open(os.path.join(path2, "transformer", "config.json")))["arch"] == cfg["arch"]
+    assert not os.path.islink(os.path.join(path2, "transformer", "config.json"))
+    # schedulers by directory config and by object
+    sched_dir = tmp_path / "sched"
+    os.makedirs(sched_dir)
+    json.dump({"_noise_class_name": "FlowMatchEulerDiscreteScheduler", "_sample_class_name": "DDPMScheduler", "shift": 1.0,
+               "num_train_timesteps": 1000}, open(sched_dir / "scheduler_config.json", "w"))
+    assert type(build_diffusion_scheduler(str(sched_dir))).__name__ == "FlowMatchEulerDiscreteScheduler"
+    assert type(build_diffusion_scheduler(str(sched_dir), sample=True)).__name__ == "DDPMScheduler"
+    clone = build_diffusion_scheduler(FlowMatchEulerDiscreteScheduler(shift=3.0))
+    assert clone.config.shift == 3.0 and build_diffusion_scheduler(None) is None
+
+
 def test_guidance_le_one_runs_single_pass(gold):
     m = gold.meta
     pipe = NOVAPipeline(transformer=build_from_golden(gold), scheduler=FlowMatchEulerDiscreteScheduler())

@@ -1,0 +1,111 @@
+"""rocprofv3 counter CSVs of tools/pmc_collect.sh -> one JSON per round under profiles/ (what bench.py's
+`roofline.traffic` and DESIGN.md section 5 cite).
+
+    python3 tools/pmc_summary.py gpurun_out/r2/pmc profiles/r02_pmc.json
+
+Per kernel (mean over the dispatches after the first = warm-up): raw counters, launch duration from the trace pass, and
+  hbm_bytes        2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024   (gfx950: FETCH_SIZE reads half the bytes of wide coalesced
+                   reads, WRITE_SIZE exact for 16-byte stores - MI355X_MICROARCH.md "HBM")
+  clock_ghz        GRBM_GUI_ACTIVE / 8 / duration               (summed over the 8 XCDs)
+  mfma_pipe_util   SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): share of SIMD-cycles with the matrix pipe busy
+  valu_active, wait_any, wait_inst, active_any: shares of SQ_WAVE_CYCLES (all quad-cycle counters)
+  mfma_valu_coexec SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES
+The file carries the sha256 of the kernel sources it was measured on; bench.py ignores it when the sources have changed.
+"""
+import csv
+import glob
+import hashlib
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nova_pointcloud_amd", "csrc")
+SIMDS = 1024
+
+
+def source_hash():
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
+def short(name):
+    m = re.match(r"(?:void )?(?:nova::)?([A-Za-z0-9_]+)(<[^(]*>)?", name)
+    tmpl = (m.group(2) or "").replace("unsigned short", "bf16").replace(" ", "")
+    return m.group(1) + tmpl
+
+
+def counters(root):
+    acc = defaultdict(lambda: defaultdict(dict))  # kernel -> counter -> dispatch -> value
+    for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k, c, d = short(row["Kernel_Name"]), row["Counter_Name"], int(row["Dispatch_Id"])
+                acc[k][c][d] = acc[k][c].get(d, 0.0) + float(row["Counter_Value"])
+    return acc
+
+
+def durations(root):
+    out = defaultdict(list)
+    for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                out[short(row["Kernel_Name"])].append((int(row["Dispatch_Id"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+    return out
+
+
+def mean_skip_first(d):
+    vals = [v for _, v in sorted(d.items() if isinstance(d, dict) else d)]
+    vals = vals[1:] if len(vals) > 1 else vals
+    return sum(vals) / len(vals)
+
+
+def main():
+    root, out_path = sys.argv[1], sys.argv[2]
+    acc, dur = counters(root), durations(root)
+    kernels = {}
+    for k in sorted(acc):
+        if not k.startswith(("attn_", "gemm", "row_norm")):
+            continue
+        raw = {c: mean_skip_first(v) for c, v in acc[k].items()}
+        rec = {"counters": {c: round(v, 1) for c, v in sorted(raw.items())}}
+        if k in dur:
+            rec["duration_us"] = round(mean_skip_first(dur[k]), 2)
+        g = lambda c: raw.get(c)
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            rec["hbm_bytes"] = round(2 * g("FETCH_SIZE") * 1024 + g("WRITE_SIZE") * 1024)
+            rec["fetch_bytes"], rec["write_bytes"] = round(2 * g("FETCH_SIZE") * 1024), round(g("WRITE_SIZE") * 1024)
+        if g("GRBM_GUI_ACTIVE") and rec.get("duration_us"):
+            cyc = g("GRBM_GUI_ACTIVE") / 8
+            rec["clock_ghz"] = round(cyc / rec["duration_us"] / 1e3, 3)
+            if g("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+                rec["mfma_pipe_util"] = round(g("SQ_VALU_MFMA_BUSY_CYCLES") / (SIMDS * cyc), 4)
+        wc = g("SQ_WAVE_CYCLES")
+        if wc:
+            for name, c in (("valu_active", "SQ_ACTIVE_INST_VALU"),):
+                if g(c) is not None:
+                    rec[name] = round(g(c) / wc, 4)
+        if g("SQ_VALU_MFMA_BUSY_CYCLES") and g("SQ_VALU_MFMA_COEXEC_CYCLES") is not None:
+            rec["mfma_valu_coexec"] = round(g("SQ_VALU_MFMA_COEXEC_CYCLES") / g("SQ_VALU_MFMA_BUSY_CYCLES"), 4)
+        if g("SQ_INSTS_MFMA") and g("SQ_INSTS_VALU") is not None:
+            rec["valu_per_mfma"] = round((g("SQ_INSTS_VALU") - g("SQ_INSTS_MFMA")) / g("SQ_INSTS_MFMA"), 2)
+        act = g("SQ_ACTIVE_INST_ANY")
+        if act is not None and g("SQ_WAIT_ANY") is not None and g("SQ_WAIT_INST_ANY") is not None:
+            tot = act + g("SQ_WAIT_ANY") + g("SQ_WAIT_INST_ANY")  # ~ SQ_WAVE_CYCLES of that pass (disjoint buckets)
+            rec.update(active_any=round(act / tot, 4), wait_any=round(g("SQ_WAIT_ANY") / tot, 4), wait_inst=round(g("SQ_WAIT_INST_ANY") / tot, 4))
+        kernels[k] = rec
+    doc = {"source_sha256": source_hash(), "shape": "one ViT block, S=64 x L=2560, D=1024, 16 heads, bf16 (tools/pmc_kernels.py)",
+           "units": __doc__.split("Per kernel")[1].strip(), "kernels": kernels}
+    with open(out_path, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    for k, r in kernels.items():
+        print(k, {a: b for a, b in r.items() if a != "counters"})
+
+
+if __name__ == "__main__":
+    main()
