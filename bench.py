@@ -31,6 +31,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled MFMA), same table
 
 WORKLOADS = {
     # name: (width, heads, latent H, W, per-GPU batch)   N = H*W points, Nv = N/4 condition tokens
@@ -151,7 +152,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = workload default)")
     ap.add_argument("--ar-steps", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=25)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8: bf16 model with the encoder's QKV / fc1 / fc2 GEMMs on the block-scaled fp8 MFMA (configs[4]; never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="rehearse the multi-process control flow on CPU (gloo, PyTorch module path, f32): not a measurement")
@@ -184,7 +186,8 @@ def main():
 
     width, heads, H, W, B = WORKLOADS[args.workload]
     B = args.batch or B
-    dtype = torch.float32 if dry else (torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    dtype = torch.float32 if (dry or args.dtype == "f32") else torch.bfloat16
+    call_extra = {"gemm_dtype": "fp8"} if args.dtype == "fp8" else {}
     pipe = build_pipeline(width, heads, H, W, dtype, device)
     # the GLOBAL batch of prompts and ONE seed on every rank: each rank generates its contiguous block of samples and draws
     # the order / noise tensors of the global batch (sharding.py: sharded(seed) == unsharded(seed))
@@ -197,7 +200,7 @@ def main():
         # per-rank pipeline call on its shard + the path's only exchange: all_gather of the generated point sets
         # (RCCL over xGMI; no collective at N = 1)
         return generate_sharded(pipe, prompts, rank, world, num_inference_steps=args.ar_steps,
-                                num_diffusion_steps=args.diffusion_steps, guidance_scale=5, generator=gen, **extra)
+                                num_diffusion_steps=args.diffusion_steps, guidance_scale=5, generator=gen, **call_extra, **extra)
 
     def fence():
         if world > 1:
@@ -256,17 +259,22 @@ def main():
         # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read from inside
         # the process); the committed summary is for the largest launch of that kernel, so it is reported with its context.
         traffic, traffic_note = pmc_traffic(dom, args.workload)
+        # fp8 mode: the fc1 (+GELU) and QKV (+RoPE) kernels are pure fp8 launches -> dense fp8 peak; attention is bf16; the
+        # "gemm_bias" slot mixes the bf16 out-projection with the fp8 fc2 and is priced at the bf16 peak
+        peak = MFMA_FP8_PEAK_TFLOPS if (args.dtype == "fp8" and dom in ("gemm_bias_gelu", "qkv_gemm_rope")) else MFMA_BF16_PEAK_TFLOPS
+        if args.dtype == "fp8":
+            traffic, traffic_note = None, "PMC passes are taken in bf16 mode"
         rec = {
             "metric": "generated points/sec/node, NOVA-d48w1024 @2048 pts, 64-step sample" if args.workload.startswith("d48w1024")
             else f"generated points/sec/node, {args.workload}",
             "value": round(value, 2), "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": "fp8 (QKV / fc1 / fc2 GEMMs) + bf16" if args.dtype == "fp8" else args.dtype, "data": "synthetic",
             "config": {"workload": args.workload, "points_per_sample": N, "ar_steps": len(schedule),
                        "diffusion_steps": args.diffusion_steps, "batch_per_gpu": B, "global_batch": world * B,
                        "guidance": "cfg 2-pass", "sharding": f"batch rows over {world} GPU(s), all_gather of points"},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["rate"], "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(mfma[dom]["rate"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["rate"], "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(mfma[dom]["rate"] / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": round(mfma[dom]["ms"] / mfma[dom]["launches"], 4),
                          "share_of_step_time": round(mfma[dom]["ms"] / 1e3 / prof_elapsed, 3),
                          "timing": "HIP events on the launch stream; one extra pass of the same step after the timed region with the "

@@ -192,6 +192,33 @@ int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, 
                             int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
                             void* ws_h, int dtype, void* stream);
 
+/* MX-fp8 weights of one block's three large GEMMs (BASELINE configs[4]): OCP e4m3 bytes in nn.Linear's [N][K] layout
+ * + one float32 scale per output row (w = w8 * ws[n]), made once with nova_quantize_rows_fp8 on the bf16 weights. */
+typedef struct {
+  const void* qkv_w8;  const float* qkv_ws;   /* [3D, D], [3D] */
+  const void* fc1_w8;  const float* fc1_ws;   /* [4D, D], [4D] */
+  const void* fc2_w8;  const float* fc2_ws;   /* [D, 4D], [D]  */
+} nova_vit_block_fp8;
+
+/* Building blocks of the fp8 stack, exposed for tests: the post-norm residual LayerNorm (vision_transformer.py:78-82,91-92)
+ * that also emits its bf16 output row as e4m3 + per-row scale, bit-compatible with nova_quantize_rows_fp8(out); and the
+ * fused QKV projection on fp8 operands with the RoPE / q-scale epilogue of nova_qkv_rope (bf16 result). */
+int nova_row_norm_fp8(const void* in, void* out, const float* gamma, const float* beta, const void* res, void* out8, float* out8_scale,
+                      long rows, int D, float eps, void* stream);
+int nova_qkv_rope_fp8(const void* x8, const float* x_scale, const void* w8, const float* w_scale, const float* bias, const float* rope,
+                      void* qkv, int S, int L, int D, int heads, int rope_batch, float q_scale, void* stream);
+
+/* nova_vit_blocks_forward with the fused-QKV, fc1 and fc2 GEMMs of every block on the block-scaled fp8 MFMA
+ * (v_mfma_scale_f32_16x16x128_f8f6f4, 2x the bf16 rate): activations are quantised per row on the fly (the residual
+ * stream by the LayerNorm kernel that produces it, the MLP hidden rows by one pass), f32 accumulation, bf16 results;
+ * attention, its out-projection, the LayerNorms and the residual stream are as in the bf16 stack. `blocks` supplies the
+ * biases, norms and the bf16 out-projection, `q` the fp8 weights. bf16 activations only. The reference has no fp8 path:
+ * results are compared with the bf16 stack (tests), not with the reference. Extra workspaces: ws_x8 [S*L, D] bytes,
+ * ws_xs [S*L] f32, ws_h8 [S*L, hidden] bytes, ws_hs [S*L] f32. Needs D, hidden % 256 == 0 and L >= 16. */
+int nova_vit_blocks_forward_fp8(const nova_vit_block* blocks, const nova_vit_block_fp8* q, int nblocks, void* x, int S, int L, int D,
+                                int heads, int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
+                                void* ws_h, void* ws_x8, float* ws_xs, void* ws_h8, float* ws_hs, void* stream);
+
 /* The same block stack for the conditioning encoder of multi-frame generation (max_latent_length > 1): the k | v rows
  * each block's fused QKV projection produces for the L rows of x are appended to that block's cache and attention runs
  * over cache_len + L keys (vision_transformer.py:55-60: `torch.cat([cache_kv, k], dim=2)`; enable_kvcache :125-126).
@@ -253,11 +280,14 @@ typedef struct {
  *                    step (they echo x_t in the reference and enter both norms), ws_v [2*B*n*P] f32 scratch
  *                    ([3*B*n*P] with 3-pass guidance).
  * S = 2B when any sched[i].guidance > 1 (cond rows then uncond rows; 3B with a third guidance pass), else S = B.
- * Workspaces in `dtype`: ws_a, ws_u, ws_h, ws_f, ws_g [S*n, D]; ws_mod [S*n, (3*depth+2)*D]. */
+ * Workspaces in `dtype`: ws_u, ws_h, ws_f, ws_g [S*n, D]; ws_a [mod_steps*S*n, D]; ws_mod [mod_steps*S*n, (3*depth+2)*D].
+ * mod_steps = 1: the AdaLN projection of SiLU(zc + temb[i]) (normalization.py:35) is computed inside every step;
+ * mod_steps = steps: for all steps in ONE GEMM ahead of the loop (the condition rows do not change during the loop,
+ * diffusion_mlp.py:93-95), which needs the steps-times larger ws_a / ws_mod. Same results either way. */
 int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
                          const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
-                         void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int dtype,
-                         void* stream);
+                         void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int mod_steps,
+                         int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -303,6 +303,78 @@ int nova_vit_blocks_forward(const nova_vit_block* blocks, int nblocks, void* x, 
                     (hipStream_t)stream);
 }
 
+int nova_row_norm_fp8(const void* in, void* out, const float* gamma, const float* beta, const void* res, void* out8, float* out8_scale,
+                      long rows, int D, float eps, void* stream) {
+  NOVA_REQUIRE(rows == 0 || (in && out && out8 && out8_scale), NOVA_ERR_ARG, "row_norm_fp8: null pointer");
+  RowNormArgs a{in, out, gamma, beta, nullptr, 0, -1, -1, -1, res, nullptr, rows, D, eps};
+  a.out8 = out8;
+  a.out8_scale = out8_scale;
+  return row_norm(a, NOVA_BF16, (hipStream_t)stream);
+}
+
+int nova_qkv_rope_fp8(const void* x8, const float* x_scale, const void* w8, const float* w_scale, const float* bias, const float* rope,
+                      void* qkv, int S, int L, int D, int heads, int rope_batch, float q_scale, void* stream) {
+  NOVA_REQUIRE(S * L == 0 || (x8 && x_scale && w8 && w_scale && qkv), NOVA_ERR_ARG, "qkv_rope_fp8: null pointer");
+  NOVA_REQUIRE(heads > 0 && D % heads == 0, NOVA_ERR_SHAPE, "qkv_rope_fp8: D %% heads != 0");
+  return gemm256_fp8_launch(x8, x_scale, w8, w_scale, bias, qkv, S * L, 3 * D, D, 3, (hipStream_t)stream, rope, L, rope_batch, D / heads,
+                            rope ? 2 * D : 0, q_scale, q_scale != 1.0f ? D : 0);
+}
+
+// The block stack with the three large GEMMs of every block (fused QKV, fc1, fc2 = 11/12 of a block's GEMM FLOPs) on the
+// MX-fp8 MFMA path (BASELINE configs[4]): weights quantised once per output row at pack time, activations quantised per
+// row on the fly - the residual stream by the LayerNorm kernel that produces it (fp8 side output), the MLP hidden rows by
+// one quantisation pass. Attention, its out-projection, LayerNorm statistics and the residual stream stay bf16 / f32.
+int nova_vit_blocks_forward_fp8(const nova_vit_block* blocks, const nova_vit_block_fp8* q, int nblocks, void* x, int S, int L, int D,
+                                int heads, int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
+                                void* ws_h, void* ws_x8, float* ws_xs, void* ws_h8, float* ws_hs, void* stream) {
+  NOVA_REQUIRE(nblocks == 0 || (blocks && q && x && ws_qkv && ws_a && ws_b && ws_h && ws_x8 && ws_xs && ws_h8 && ws_hs), NOVA_ERR_ARG,
+               "vit_blocks_fp8: null pointer");
+  NOVA_REQUIRE(heads > 0 && D % heads == 0, NOVA_ERR_SHAPE, "vit_blocks_fp8: D %% heads != 0");
+  NOVA_REQUIRE(D % 256 == 0 && hidden % 256 == 0, NOVA_ERR_SHAPE, "vit_blocks_fp8: D and hidden must be multiples of 256");
+  NOVA_REQUIRE(!rope || L >= 16, NOVA_ERR_SHAPE, "vit_blocks_fp8: L >= 16 with RoPE");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = S * L, hd = D / heads;
+  if (M == 0 || nblocks == 0) return 0;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const char* qkv = static_cast<const char*>(ws_qkv);
+  struct Walk {
+    int k = 0;
+    void next() { walk_reverse(g_walk_alternate && (k++ & 1)); }
+    ~Walk() { walk_reverse(false); }
+  } walk;
+  NOVA_TRY(quantize_rows_fp8(x, ws_x8, ws_xs, M, D, st));  // the stack's input rows; later ones come from the LN kernels
+  for (int i = 0; i < nblocks; ++i) {
+    const nova_vit_block& b = blocks[i];
+    const nova_vit_block_fp8& w = q[i];
+    walk.next();
+    NOVA_TRY(gemm256_fp8_launch(ws_x8, ws_xs, w.qkv_w8, w.qkv_ws, b.qkv_b, ws_qkv, M, 3 * D, D, 3 /* RoPE + q-scale */, st, rope, L,
+                                rope_batch, hd, rope ? 2 * D : 0, scale * 1.4426950408889634f, D));
+    walk.next();
+    NOVA_TRY(attn_fwd(qkv, qkv + (size_t)D * 2, qkv + (size_t)2 * D * 2, ws_a, S, heads, L, L, hd, 3L * D, 3L * D, D, scale, NOVA_BF16,
+                      st, true));
+    walk.next();
+    NOVA_TRY(gemm_bias_act(ws_a, b.proj_w, b.proj_b, ws_b, M, D, D, NOVA_ACT_NONE, NOVA_BF16, st));
+    RowNormArgs n1{ws_b, x, b.norm1_w, b.norm1_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
+    n1.out8 = ws_x8;
+    n1.out8_scale = ws_xs;
+    walk.next();
+    NOVA_TRY(row_norm(n1, NOVA_BF16, st));
+    walk.next();
+    NOVA_TRY(gemm256_fp8_launch(ws_x8, ws_xs, w.fc1_w8, w.fc1_ws, b.fc1_b, ws_h, M, hidden, D, NOVA_ACT_GELU_ERF, st));
+    NOVA_TRY(quantize_rows_fp8(ws_h, ws_h8, ws_hs, M, hidden, st));
+    walk.next();
+    NOVA_TRY(gemm256_fp8_launch(ws_h8, ws_hs, w.fc2_w8, w.fc2_ws, b.fc2_b, ws_b, M, D, hidden, NOVA_ACT_NONE, st));
+    RowNormArgs n2{ws_b, x, b.norm2_w, b.norm2_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
+    if (i + 1 < nblocks) {  // the next block's QKV input
+      n2.out8 = ws_x8;
+      n2.out8_scale = ws_xs;
+    }
+    walk.next();
+    NOVA_TRY(row_norm(n2, NOVA_BF16, st));
+  }
+  return 0;
+}
+
 int nova_vit_blocks_forward_kv(const nova_vit_block* blocks, int nblocks, void* x, int S, int L, int D, int heads,
                                int hidden, const float* rope, int rope_batch, void* kv_cache, long cache_cap,
                                long cache_len, void* ws_qkv, void* ws_a, void* ws_b, void* ws_h, int dtype, void* stream) {
@@ -337,8 +409,8 @@ int nova_modulate_rows(const void* x, const void* mod, void* out, long rows, int
 
 int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
                          const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
-                         void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int dtype,
-                         void* stream) {
+                         void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int mod_steps,
+                         int dtype, void* stream) {
   NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "decoder_denoise: bad dtype %d", dtype);
   NOVA_REQUIRE(dec && zc && temb && x && sched && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
                "decoder_denoise: null pointer");
@@ -351,6 +423,17 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
   const int depth = dec->depth;
   const long mod_ld = (long)(3 * depth + 2) * D;
   const size_t nP = (size_t)B * n * P;
+  NOVA_REQUIRE(mod_steps == 1 || mod_steps == steps, NOVA_ERR_ARG, "decoder_denoise: mod_steps must be 1 or steps");
+  // mod_steps == steps: the AdaLN projections of ALL steps in one GEMM ahead of the loop (M = steps * S * n rows: the large-M
+  // kernel at ~2.5x the rate of the per-step small-M launches, and two launches fewer per step). Rows are laid out per
+  // step for the full S sequences; a step that runs fewer guidance passes (guidance_trunc) reads its leading rows.
+  const bool hoist = mod_steps == steps && steps > 1;
+  const long rows_all = (long)S * n;
+  if (hoist) {
+    NOVA_TRY(silu_add_steps(zc, temb, ws_a, rows_all, steps, D, dtype, st));
+    NOVA_TRY(gemm_bias_act(ws_a, dec->adaln_w, dec->adaln_b, ws_mod, (int)(rows_all * steps), (int)mod_ld, D, NOVA_ACT_NONE, dtype, st));
+  }
+  void* const ws_mod_base = ws_mod;
   for (int i = 0; i < steps; ++i) {
     const SamplerStep sp{sched[i].guidance, sched[i].kx,    sched[i].kv,          sched[i].clip,      sched[i].c0,
                          sched[i].cx,       sched[i].sigma, sched[i].extra_scale, sched[i].extra_kind};
@@ -362,8 +445,12 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
                  NOVA_ERR_ARG, "decoder_denoise: guidance renorm is built for the flow-matching Euler step only");
     const int Se = passes * B;
     const long rows = (long)Se * n;
-    NOVA_TRY(silu_add_rows(zc, static_cast<const char*>(temb) + (size_t)i * D * es, ws_a, rows, D, dtype, st));
-    NOVA_TRY(gemm_bias_act(ws_a, dec->adaln_w, dec->adaln_b, ws_mod, (int)rows, (int)mod_ld, D, NOVA_ACT_NONE, dtype, st));
+    if (hoist) {
+      ws_mod = static_cast<char*>(ws_mod_base) + (size_t)i * rows_all * mod_ld * es;
+    } else {
+      NOVA_TRY(silu_add_rows(zc, static_cast<const char*>(temb) + (size_t)i * D * es, ws_a, rows, D, dtype, st));
+      NOVA_TRY(gemm_bias_act(ws_a, dec->adaln_w, dec->adaln_b, ws_mod, (int)rows, (int)mod_ld, D, NOVA_ACT_NONE, dtype, st));
+    }
     NOVA_TRY(patch_embed_rows(x, dec->patch_w, dec->patch_b, ws_u, Se, B, n, P, D, dtype, st));
     for (int b = 0; b < depth; ++b) {
       const nova_mlp_block& blk = dec->blocks[b];

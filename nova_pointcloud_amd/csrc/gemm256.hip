@@ -691,12 +691,17 @@ static int launch256p(const void* A, const void* W, void* C, int M, int N, int K
 }
 
 // MX-fp8 operands (OCP e4m3 bytes, K % 128 == 0), bf16 result; persistent kernel only. Internal entry for capi.hip.
+// epi E_ROPE: the fused-QKV epilogue (rotation of the first rope_cols columns with the [rope_batch, L, hd/2, 2] table,
+// q_scale on the first q_cols columns), applied after the dequantisation scales and the bias.
 int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, void* C, int M,
-                       int N, int K, int epi, hipStream_t st) {
+                       int N, int K, int epi, hipStream_t st, const float* rope, int L, int rope_batch, int hd, int rope_cols,
+                       float q_scale, int q_cols) {
   if (M <= 0) return 0;
   if (N % 256 != 0 || K % 128 != 0 || K <= 0) return set_error(NOVA_ERR_SHAPE, "gemm_fp8: need N %% 256 == 0 and K %% 128 == 0 (got N=%d K=%d)", N, K);
-  if (epi == E_ROPE) return set_error(NOVA_ERR_ARG, "gemm_fp8: no RoPE epilogue");
-  GemmEpi256 e{bias, nullptr, 1, 1, 1, 0, 1.0f, 0, g_gm256, walk_is_reverse() ? 1 : 0, sa, sw, 0};
+  if (epi == E_ROPE && (rope_cols % 256 || q_cols % 256 || (rope && (L < 16 || rope_batch <= 0 || hd <= 0))))
+    return set_error(NOVA_ERR_SHAPE, "gemm_fp8: RoPE epilogue needs rope_cols, q_cols %% 256 == 0 and L >= 16");
+  GemmEpi256 e{bias, rope, rope ? L : 1, rope ? rope_batch : 1, rope ? hd : 2, rope ? rope_cols : 0, q_scale, q_cols, g_gm256,
+               walk_is_reverse() ? 1 : 0, sa, sw, 0};
   const int ntm = (M + 255) / 256, ntn = N / 256;
   dim3 grid(cu_slots()), block(512);
   ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
@@ -707,6 +712,7 @@ int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const fl
     case E_NONE: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     case E_GELU: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     case E_SILU: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_ROPE: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     default: return set_error(NOVA_ERR_ARG, "gemm_fp8: unknown epilogue %d", epi);
   }
   return check_launch("gemm256p fp8");

@@ -57,6 +57,8 @@ struct RowNormArgs {
   int D;
   float eps;
   int rev = 0;           // set by row_norm() from walk_is_reverse(); callers leave it
+  void* out8 = nullptr;  // bf16 only, optional: the output row once more as OCP e4m3 bytes [rows, D] with the per-row
+  float* out8_scale = nullptr;  // scale amax / 448 [rows] (the fp8 A operand of the next GEMM; same rule as quantize_rows_fp8)
 };
 int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
 
@@ -70,8 +72,10 @@ int scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B,
                    int dtype, hipStream_t st);
 int quantize_rows_fp8(const void* x, void* out, float* scale, long rows, int D, hipStream_t st);
 int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, void* C, int M,
-                       int N, int K, int epi, hipStream_t st);
+                       int N, int K, int epi, hipStream_t st, const float* rope = nullptr, int L = 1, int rope_batch = 1,
+                       int hd = 2, int rope_cols = 0, float q_scale = 1.0f, int q_cols = 0);
 int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, hipStream_t st);
+int silu_add_steps(const void* a, const void* vecs, void* out, long rows, int nvec, int D, int dtype, hipStream_t st);
 int timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, hipStream_t st);
 int patch_embed_rows(const float* x, const void* w, const float* bias, void* out, int S, int B, int n, int P, int D,
                      int dtype, hipStream_t st);

@@ -45,6 +45,7 @@ template <> struct Chunk<float> {
   f4v v[1];
   static __device__ __forceinline__ Chunk load(const float* p) { Chunk c; c.v[0] = *reinterpret_cast<const f4v*>(p); return c; }
   __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f4v*>(p) = v[0]; }
+  __device__ __forceinline__ Chunk rounded() const { return *this; }
 };
 template <> struct Chunk<bf16_t> {
   static constexpr int N = 8;
@@ -59,6 +60,13 @@ template <> struct Chunk<bf16_t> {
   __device__ __forceinline__ void store(bf16_t* p) const {
     u4v u = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]), pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
     *reinterpret_cast<u4v*>(p) = u;
+  }
+  __device__ __forceinline__ Chunk rounded() const {  // the values as they read back after store(): rounded to bf16
+    const u4v u = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]), pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
+    Chunk c;
+    c.v[0] = f4v{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
+    c.v[1] = f4v{__uint_as_float(u[2] << 16), __uint_as_float(u[2] & 0xffff0000u), __uint_as_float(u[3] << 16), __uint_as_float(u[3] & 0xffff0000u)};
+    return c;
   }
 };
 
@@ -106,6 +114,8 @@ __global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
         }
   const float rstd = rsqrtf(wave_sum(sq) / (float)a.D + a.eps);
   T* out = static_cast<T*>(a.out) + row * a.D;
+  const bool q8 = sizeof(T) == 2 && a.out8 != nullptr;  // also emit the row as e4m3 + scale (what the next fp8 GEMM reads)
+  float amax = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int d = (it * 64 + lane) * C::N;
@@ -121,6 +131,39 @@ __global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
         y.v[k] = v;
       }
       y.store(out + d);
+      if (q8) {  // quantise what was STORED (the bf16-rounded row), so the fp8 copy equals quantize_rows_fp8(out)
+        y = y.rounded();
+        x[it] = y;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(y.v[k][j]));
+      }
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (q8) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+      const float inv = 1.0f / sc;
+      if (lane == 0) a.out8_scale[row] = sc;
+      uint8_t* o8 = static_cast<uint8_t*>(a.out8) + row * a.D;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int d = (it * 64 + lane) * C::N;
+        if (d < a.D) {
+          u2v o;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(x[it].v[k % NV][0] * inv, x[it].v[k % NV][1] * inv, w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(x[it].v[k % NV][2] * inv, x[it].v[k % NV][3] * inv, w, true);
+            o[k] = (uint32_t)w;
+          }
+          *reinterpret_cast<u2v*>(o8 + d) = o;
+        }
+      }
     }
   }
 }
@@ -142,6 +185,7 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
                 (a.gate_off >= 0 && a.gate_off % vec)))
     return set_error(NOVA_ERR_SHAPE, "row_norm: modulation offsets must be multiples of %d", vec);
   if ((a.gamma == nullptr) != (a.beta == nullptr)) return set_error(NOVA_ERR_ARG, "row_norm: gamma/beta must come together");
+  if (a.out8 && (dtype != NOVA_BF16 || !a.out8_scale)) return set_error(NOVA_ERR_ARG, "row_norm: the fp8 side output needs bf16 rows and a scale buffer");
   dim3 grid((unsigned)((a.rows + 3) / 4));
   RowNormArgs ar = a;
   ar.rev = walk_is_reverse() ? 1 : 0;
@@ -381,6 +425,33 @@ int quantize_rows_fp8(const void* x, void* out, float* scale, long rows, int D, 
   hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, (uint8_t*)out, scale,
                      rows, D);
   return check_launch("quantize_rows_fp8");
+}
+
+// out[i * rows + r][:] = silu(a[r][:] + vecs[i][:]) for i < nvec: the SiLU(z + t_i) rows of ALL diffusion steps at once, so that
+// their AdaLN projections become one large GEMM (M = steps * rows) instead of one small GEMM per step.
+template <typename T>
+__global__ __launch_bounds__(256) void silu_add_steps_kernel(const T* __restrict__ a, const T* __restrict__ vecs, T* __restrict__ out,
+                                                             long per_step4, long total4, int D) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const long step = i / per_step4, e = (i - step * per_step4) * 4;
+    const int d = (int)(e % D);
+    f4v x = Vec4<T>::load(a + e) + Vec4<T>::load(vecs + step * D + d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = silu(x[j]);
+    Vec4<T>::store(out + i * 4, x);
+  }
+}
+
+int silu_add_steps(const void* a, const void* vecs, void* out, long rows, int nvec, int D, int dtype, hipStream_t st) {
+  if (rows <= 0 || nvec <= 0) return 0;
+  if (D % 4) return set_error(NOVA_ERR_SHAPE, "silu_add_steps: D %% 4 != 0");
+  const long per4 = rows * D / 4, total4 = per4 * nvec;
+  const int blocks = (int)((total4 + 255) / 256 > 16384 ? 16384 : (total4 + 255) / 256);
+  if (dtype == NOVA_BF16)
+    hipLaunchKernelGGL(silu_add_steps_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)vecs, (bf16_t*)out, per4, total4, D);
+  else
+    hipLaunchKernelGGL(silu_add_steps_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)vecs, (float*)out, per4, total4, D);
+  return check_launch("silu_add_steps");
 }
 
 int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, hipStream_t st) {

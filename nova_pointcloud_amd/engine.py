@@ -64,6 +64,23 @@ def pack_vit_blocks(blocks, dtype):
             pk.f(b.norm1.weight), pk.f(b.norm1.bias), pk.w(b.mlp.fc1.weight, dtype), pk.f(b.mlp.fc1.bias),
             pk.w(b.mlp.fc2.weight, dtype), pk.f(b.mlp.fc2.bias), pk.f(b.norm2.weight), pk.f(b.norm2.bias))
     pk.arr = arr
+    pk.modules = list(blocks)
+    return pk
+
+
+def pack_vit_blocks_fp8(blocks):
+    """nova_vit_block_fp8[]: the fused-QKV, fc1 and fc2 weights of every block as OCP e4m3 bytes + one scale per output row
+    (amax / 448), quantised once here from the bf16 parameters (BASELINE configs[4]; the reference has no fp8 path)."""
+    pk = _Pack()
+    arr = (hip.VitBlockFp8 * len(blocks))()
+    for i, b in enumerate(blocks):
+        fields = []
+        for lin in (b.attn.qkv, b.mlp.fc1, b.mlp.fc2):
+            w8, ws = hip.quantize_rows_fp8(lin.weight.detach().to(torch.bfloat16).contiguous())
+            pk.keep += [w8, ws]
+            fields += [w8.data_ptr(), ws.data_ptr()]
+        arr[i] = hip.VitBlockFp8(*fields)
+    pk.arr = arr
     return pk
 
 
@@ -159,6 +176,7 @@ class NovaEngine(object):
         hip.load()
         self.model = model
         self.sig = None
+        self.fp8 = False
         self.ws_key, self.ws = None, {}
 
     # ------------------------------------------------------------------ packing / workspaces
@@ -217,28 +235,42 @@ class NovaEngine(object):
                           pk.f(vpe.time_proj[2].bias), pk.f(vpe.norm.weight), pk.f(vpe.norm.bias))
         self.sig = sig
 
-    def _workspace(self, S, B, N, L, nmax, lane=0):
-        key = (S, B, N, L, nmax, self.dtype, self.dev)
+    # AdaLN projections of all diffusion steps in one GEMM (nova_decoder_denoise mod_steps = steps) when the steps-times
+    # larger modulation buffer stays under this many bytes per lane (config C: 3.3 GB; 288 GB of HBM per GPU)
+    MOD_HOIST_BYTES = 12 << 30
+
+    def _workspace(self, S, B, N, L, nmax, lane=0, steps=1):
+        key = (S, B, N, L, nmax, self.dtype, self.dev, self.fp8, steps)
         if lane:  # additional lanes keep their own buffers
             cache = self.__dict__.setdefault("_lane_ws", {})
             if cache.get(lane, (None, None))[0] != key:
                 saved = (self.ws_key, self.ws)
                 self.ws_key = None
-                cache[lane] = (key, dict(self._workspace(S, B, N, L, nmax)))
+                cache[lane] = (key, dict(self._workspace(S, B, N, L, nmax, 0, steps)))
                 self.ws_key, self.ws = saved
             return cache[lane][1]
         if key != self.ws_key:
             D, dt, dev = self.D, self.dtype, self.dev
             e = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
             rows = S * L
-            self.ws = dict(x1=e(rows, D), x2=e(rows, D), qkv=e(rows, 3 * D), a=e(rows, D), b=e(rows, D),
-                           h=e(rows, self.hidden), z0=e(B * N, D), da=e(S * nmax, D), du=e(S * nmax, D), dh=e(S * nmax, D),
-                           df=e(S * nmax, D), dg=e(S * nmax, D), dmod=e(S * nmax, (3 * self.dec.depth + 2) * D))
+            self.ws = dict(x8=torch.empty(rows, D, dtype=torch.uint8, device=dev), xs=torch.empty(rows, dtype=_F32, device=dev),
+                           h8=torch.empty(rows, self.hidden, dtype=torch.uint8, device=dev), hs=torch.empty(rows, dtype=_F32, device=dev)) if self.fp8 else {}
+            self.ws.update(x1=e(rows, D), x2=e(rows, D), qkv=e(rows, 3 * D), a=e(rows, D), b=e(rows, D),
+                           h=e(rows, self.hidden), z0=e(B * N, D), da=e(steps * S * nmax, D), du=e(S * nmax, D), dh=e(S * nmax, D),
+                           df=e(S * nmax, D), dg=e(S * nmax, D), dmod=e(steps * S * nmax, (3 * self.dec.depth + 2) * D))
             self.ws_key = key
         return self.ws
 
     # ------------------------------------------------------------------ building blocks
     def _blocks(self, pack, x, S, L, rope, rope_batch, ws):
+        if self.fp8 and L >= 16:  # QKV / fc1 / fc2 on the block-scaled fp8 MFMA (inputs["gemm_dtype"] == "fp8")
+            q = pack.__dict__.get("fp8")
+            if q is None:
+                q = pack.fp8 = pack_vit_blocks_fp8(pack.modules)
+            hip.call("nova_vit_blocks_forward_fp8", pack.arr, q.arr, len(pack.arr), x.data_ptr(), S, L, self.D, self.heads, self.hidden,
+                     hip.ptr(rope), rope_batch, ws["qkv"].data_ptr(), ws["a"].data_ptr(), ws["b"].data_ptr(), ws["h"].data_ptr(),
+                     ws["x8"].data_ptr(), ws["xs"].data_ptr(), ws["h8"].data_ptr(), ws["hs"].data_ptr(), hip.stream_ptr())
+            return
         hip.call("nova_vit_blocks_forward", pack.arr, len(pack.arr), x.data_ptr(), S, L, self.D, self.heads, self.hidden,
                  hip.ptr(rope), rope_batch, ws["qkv"].data_ptr(), ws["a"].data_ptr(), ws["b"].data_ptr(),
                  ws["h"].data_ptr(), self.code, hip.stream_ptr())
@@ -310,6 +342,12 @@ class NovaEngine(object):
         reference's order, and the lanes receive row slices - results do not depend on the number of lanes.
         """
         self._refresh()
+        gemm_dtype = inputs.get("gemm_dtype", None)
+        if gemm_dtype not in (None, "bf16", "fp8"):
+            raise ValueError(f"gemm_dtype {gemm_dtype!r}: the encoder GEMMs run in the model dtype or in 'fp8'")
+        self.fp8 = gemm_dtype == "fp8"
+        if self.fp8 and (self.dtype != torch.bfloat16 or self.D % 256 or self.hidden % 256):
+            raise NotImplementedError("gemm_dtype='fp8' needs a bfloat16 model whose width and MLP width are multiples of 256")
         with torch.cuda.device(self.dev):  # launches go to the model's device whatever the caller's current device is
             return self._generate(inputs)
 
@@ -514,7 +552,9 @@ class NovaEngine(object):
         nmax = max(num_preds) if num_preds else 1
         Lp = Lt + (2 if ctx["motion"] is not None else 0)  # condition prefix: text tokens (+ flow and fps tokens)
         L2 = Nv + N
-        ws = self._workspace(S, B, N, max(L2, Lp + Nv), nmax, ctx["k"])
+        mod_bytes = steps * S * nmax * (3 * self.dec.depth + 2) * D * prompt.element_size()
+        mod_steps = steps if (steps > 1 and mod_bytes <= self.MOD_HOIST_BYTES and not inputs.get("per_step_adaln", False)) else 1
+        ws = self._workspace(S, B, N, max(L2, Lp + Nv), nmax, ctx["k"], mod_steps)
         code, st = self.code, hip.stream_ptr
         extra_kind = (1 if scaler.image_guidance_scale else 2) if passes == 3 else 0
         extra_scale = float(scaler.image_guidance_scale or scaler.spatiotemporal_guidance_scale) if passes == 3 else 0.0
@@ -647,7 +687,7 @@ class NovaEngine(object):
                 hip.call("nova_decoder_denoise", ctypes.byref(self.dec.struct), zc.data_ptr(), temb.data_ptr(), x_n.data_ptr(), plan,
                          hip.ptr(step_noise), renorm if cfg_on else 1.0, hip.ptr(echo), steps, S, B, n, P, D, ws["da"].data_ptr(),
                          ws["du"].data_ptr(), ws["dh"].data_ptr(), ws["df"].data_ptr(), ws["dg"].data_ptr(), ws["dmod"].data_ptr(),
-                         hip.ptr(ws_v), code, st())
+                         hip.ptr(ws_v), mod_steps, code, st())
                 canvas.scatter_(1, idx, x_n)
                 done += n
                 if i == len(num_preds) - 1:

@@ -34,6 +34,12 @@ class VitBlock(ctypes.Structure):
         "fc1_w", "fc1_b", "fc2_w", "fc2_b", "norm2_w", "norm2_b")]
 
 
+class VitBlockFp8(ctypes.Structure):
+    """``nova_vit_block_fp8`` (include/nova_hip.h)."""
+
+    _fields_ = [(k, c_void_p) for k in ("qkv_w8", "qkv_ws", "fc1_w8", "fc1_ws", "fc2_w8", "fc2_ws")]
+
+
 class MlpBlock(ctypes.Structure):
     """``nova_mlp_block`` (include/nova_hip.h)."""
 
@@ -73,13 +79,17 @@ SIGNATURES = {
     "nova_head_cfg_euler": [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_float, c_int, c_void_p],
     "nova_vit_blocks_forward": [ctypes.POINTER(VitBlock), c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_int]
     + [c_void_p] * 4 + [c_int, c_void_p],
+    "nova_row_norm_fp8": [c_void_p] * 7 + [c_long, c_int, c_float, c_void_p],
+    "nova_qkv_rope_fp8": [c_void_p] * 7 + [c_int] * 5 + [c_float, c_void_p],
+    "nova_vit_blocks_forward_fp8": [ctypes.POINTER(VitBlock), ctypes.POINTER(VitBlockFp8), c_int, c_void_p] + [c_int] * 5
+    + [c_void_p, c_int] + [c_void_p] * 8 + [c_void_p],
     "nova_vit_blocks_forward_kv": [ctypes.POINTER(VitBlock), c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_int]
     + [c_void_p, c_long, c_long] + [c_void_p] * 4 + [c_int, c_void_p],
     "nova_pointset_nn_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_int, c_void_p],
     "nova_pointset_pairwise_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_void_p],
     "nova_modulate_rows": [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p],
     "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]
-    + [c_int] * 6 + [c_void_p] * 7 + [c_int, c_void_p],
+    + [c_int] * 6 + [c_void_p] * 7 + [c_int, c_int, c_void_p],
 }
 SIGNATURES["nova_prof_enable"] = [c_int]
 SIGNATURES["nova_debug_force_gemm_tile"] = [c_int]

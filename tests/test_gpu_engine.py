@@ -419,3 +419,34 @@ def test_multi_frame_bf16_and_lanes(vgold, hip):
 def test_three_pass_rejects_both_scales(vgold, hip):
     with pytest.raises(ValueError):
         video_call(vgold, "cuda", torch.float32, image_guidance_scale=1.0, spatiotemporal_guidance_scale=1.0)
+
+
+def test_fp8_gemm_mode_small_model(hip):
+    """gemm_dtype='fp8' end to end on a narrow model (D = 256): close to the bf16 run under injected draws, refusals."""
+    model, sd, cfg = _tiny_model(256, 4, (8, 8), image_dim=3, stride=16, rotary=True, seed=13, depths=(1, 2, 1))
+    g = torch.Generator().manual_seed(3)
+    prompts = [torch.randn(5, 64, generator=g) * 0.5, torch.randn(3, 64, generator=g) * 0.5]
+    order = torch.stack([torch.randperm(64, generator=g) for _ in range(2)])
+    noises = [torch.randn(2, 3, 8, 8, generator=g) for _ in range(3)]
+    pipe = NOVAPipeline(transformer=model.cuda().to(torch.bfloat16), scheduler=FlowMatchEulerDiscreteScheduler())
+    kw = dict(prompt_embeds=[p.cuda().bfloat16() for p in prompts], num_inference_steps=3, num_diffusion_steps=3, guidance_scale=4.0,
+              output_type="latent", disable_progress_bar=True, pred_order=order, noise_fn=lambda i: noises[i])
+    a = pipe(**kw).frames.float()
+    b = pipe(gemm_dtype="fp8", **kw).frames.float()
+    assert torch.isfinite(b).all() and not torch.equal(a, b)
+    assert rms_rel(b, a) < 0.2
+    with pytest.raises(ValueError):
+        pipe(gemm_dtype="int4", **kw)
+    with pytest.raises(NotImplementedError):
+        NOVAPipeline(transformer=model.float(), scheduler=FlowMatchEulerDiscreteScheduler())(gemm_dtype="fp8", **kw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_adaln_projection_hoisted_over_steps_equals_per_step(gold, hip, dtype):
+    """nova_decoder_denoise mod_steps = steps (one AdaLN GEMM for all diffusion steps) against mod_steps = 1: identical
+    points, with guidance truncation switching the pass count mid-loop as well."""
+    order, noises = gold.t["out/order"][..., 0], gold.t["in/noises"]
+    for extra in ({}, {"guidance_trunc": 450.0, "guidance_renorm": 0.3}):
+        a = run_pipe(gold, dtype, pred_order=order, noise_fn=lambda i: noises[i], **extra)[1]
+        b = run_pipe(gold, dtype, pred_order=order, noise_fn=lambda i: noises[i], per_step_adaln=True, **extra)[1]
+        assert torch.equal(a, b)

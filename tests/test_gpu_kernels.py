@@ -382,3 +382,45 @@ def test_gemm_fp8_layout_asymmetric(hip):
     w8, sw = hip.quantize_rows_fp8(w)
     out = hip.gemm_fp8_bias_act(a8, sa, w8, sw, None, 0)
     assert relerr(out, _dequant(w8, sw).T.contiguous()) < 1e-2
+
+
+def test_row_norm_fp8_side_output_equals_quantised_output(hip):
+    """The LayerNorm + residual kernel's fp8 side output (the A operand of the next fp8 GEMM) is bit-for-bit what
+    nova_quantize_rows_fp8 makes of the bf16 row it stores."""
+    import ctypes
+
+    rows, D = 777, 1536
+    x, res = rnd(rows, D, dtype=torch.bfloat16, seed=81), rnd(rows, D, dtype=torch.bfloat16, seed=82)
+    g, b = 1 + rnd(D, seed=83) * 0.1, rnd(D, seed=84) * 0.1
+    plain = hip.row_norm(x, gamma=g, beta=b, res=res)
+    out = torch.empty_like(x)
+    q = torch.empty(rows, D, dtype=torch.uint8, device=DEV)
+    sc = torch.empty(rows, dtype=torch.float32, device=DEV)
+    hip.call("nova_row_norm_fp8", x.data_ptr(), out.data_ptr(), g.data_ptr(), b.data_ptr(), res.data_ptr(), q.data_ptr(), sc.data_ptr(),
+             rows, D, 1e-5, hip.stream_ptr())
+    assert torch.equal(out, plain)
+    q2, sc2 = hip.quantize_rows_fp8(out)
+    assert torch.equal(sc, sc2) and torch.equal(q, q2)
+
+
+def test_gemm_fp8_qkv_rope_epilogue(hip):
+    """fp8 fused QKV with the RoPE + q-scale epilogue against the same epilogue applied to the dequantised product."""
+    S, L, D, heads = 2, 160, 512, 8
+    hd = D // heads
+    x, w = rnd(S * L, D, dtype=torch.bfloat16, seed=91), rnd(3 * D, D, dtype=torch.bfloat16, scale=D ** -0.5, seed=92)
+    bias = rnd(3 * D, seed=93)
+    ang = torch.rand(1, L, hd // 2, device=DEV) * 6.28
+    rope = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous()
+    x8, xs = hip.quantize_rows_fp8(x)
+    w8, ws = hip.quantize_rows_fp8(w)
+    out = torch.empty(S * L, 3 * D, dtype=torch.bfloat16, device=DEV)
+    hip.call("nova_qkv_rope_fp8", x8.data_ptr(), xs.data_ptr(), w8.data_ptr(), ws.data_ptr(), bias.data_ptr(), rope.data_ptr(),
+             out.data_ptr(), S, L, D, heads, 1, 0.5, hip.stream_ptr())
+    ref = (_dequant(x8, xs).double() @ _dequant(w8, ws).double().T + bias.double()).view(S, L, 3, heads, hd // 2, 2)
+    c, s_ = rope[0, :, None, :, 0].double(), rope[0, :, None, :, 1].double()
+    rot = ref.clone()
+    for t in (0, 1):  # q and k thirds: adjacent pairs rotated
+        a, b = ref[:, :, t, ..., 0], ref[:, :, t, ..., 1]
+        rot[:, :, t, ..., 0], rot[:, :, t, ..., 1] = a * c - b * s_, a * s_ + b * c
+    rot[:, :, 0] *= 0.5  # q_scale on the q third
+    assert relerr(out, rot.reshape(S * L, 3 * D).float()) < tol(torch.bfloat16)

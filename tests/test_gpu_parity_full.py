@@ -110,3 +110,17 @@ def test_bf16_injected_draws_close_to_oracle_at_full_depth(case, hip):
     err, mx = rms_rel(x, case["ref"]), rel(x, case["ref"])
     print(f"\n[parity-full] {case['name']} bf16 injected: rms rel {err:.3e}, max rel {mx:.3e}")
     assert err < case["bf16_bound"], err
+
+
+def test_fp8_gemm_mode_against_bf16_and_oracle_at_full_depth(case, hip):
+    """BASELINE configs[4]: the encoder's QKV / fc1 / fc2 GEMMs on the block-scaled fp8 MFMA. The
+    reference has no fp8 path, so the result is compared with this build's bf16 output under the same injected order and
+    noise (rms-relative, reported), and with the f32 oracle for scale."""
+    order, noises = case["order"], case["noises"]
+    kw = dict(pred_order=order, noise_fn=lambda i: noises[i])
+    x16 = run(case, torch.bfloat16, **kw)
+    x8 = run(case, torch.bfloat16, gemm_dtype="fp8", **kw)
+    assert torch.isfinite(x8).all()
+    e_bf16, e_ref = rms_rel(x8, x16), rms_rel(x8, case["ref"])
+    print(f"\n[parity-full] {case['name']} fp8 GEMMs: rms rel vs bf16 {e_bf16:.3e}, vs f32 oracle {e_ref:.3e}")
+    assert e_bf16 < 0.25, e_bf16
