@@ -512,6 +512,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
 #pragma unroll
       for (int mf = 0; mf < 8; ++mf) sav[mf] = e.sa[min(cm0 + wr * 128 + mf * 16 + fr, M - 1)];
       asm volatile("" ::"v"(sav[7]));  // youngest of them: the compiler's wait sits here (loads retire in order)
+      // dequantise in place, ahead of everything else: the three scale / bias vectors (40 registers) are dead before the
+      // epilogue proper starts to load its RoPE rows (kept live through it they cost the RoPE variant 97 spilled VGPRs)
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < 8; ++mf) acc[nf][mf] = (acc[nf][mf] * sav[mf]) * swv[nf] + bfv[nf];
     }
     f4v cs[4][2][4];  // [group][row block][nf]
     int coff[4];      // column of this lane's 4 floats inside a table row (head-relative), per nf
@@ -548,7 +554,6 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
           f4v v = acc[nf][mf];
-          if constexpr (FP8) v = (v * sav[mf]) * swv[nf] + bfv[nf];
           if (EPI == E_GELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = sizeof(OT) == 2 ? gelu_erf_fast(v[q]) : gelu_erf(v[q]);
