@@ -63,6 +63,24 @@ def test_lr_schedules_follow_the_reference_formulas():
     assert [round(v, 6) for v in seq] == [1.0, 1.0, 0.1, 0.1, 0.01, 0.01]
 
 
+def test_lr_schedules_match_reference_values():
+    """tests/golden/lr_schedules.json: 45 steps of the reference's own ConstantLR / CosineLR / MultiStepLR objects."""
+    import json
+
+    from diffnext.engine import lr_scheduler as M
+
+    for case in json.load(open(os.path.join(ROOT, "tests", "golden", "lr_schedules.json"))):
+        sched = getattr(M, case["schedule"])(**case["kwargs"])
+        for i, want in enumerate(case["lr"]):
+            got = sched.get_lr()
+            assert abs(got - want) <= 1e-15 * max(1.0, abs(want)), (case["schedule"], i, got, want)
+            assert sched.get_lr() == got  # asking twice does not move the schedule
+            sched.step()
+        resumed = getattr(M, case["schedule"])(**case["kwargs"])
+        resumed._step_count = 30  # the Trainer sets the step count on resume
+        assert abs(resumed.get_lr() - case["lr"][30]) <= 1e-15 * max(1.0, abs(case["lr"][30]))
+
+
 class FixedBatch(object):
     def __init__(self, seed=3, B=4):
         from diffnext.engine.datasets import SyntheticPointClouds
