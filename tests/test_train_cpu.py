@@ -81,6 +81,52 @@ def test_lr_schedules_match_reference_values():
         assert abs(resumed.get_lr() - case["lr"][30]) <= 1e-15 * max(1.0, abs(case["lr"][30]))
 
 
+def test_param_groups_match_reference_function():
+    """tests/golden/param_groups.json: the reference's own get_param_groups / freeze_module / count_params on its toy model."""
+    import json
+
+    from golden_util import Golden
+    from test_mirror_cpu import build_from_golden
+
+    from diffnext.engine import engine_utils as U
+
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "param_groups.json")))
+    m = build_from_golden(Golden("tiny_rope"))  # same architecture as the generator's model
+    U.freeze_module(m.text_embed.norm), U.freeze_module(m.video_pos_embed), U.freeze_module(m.video_encoder.patch_embed)
+    m.mask_embed.mask_token.lr_scale = 0.5
+    m.image_decoder.head.bias.no_weight_decay = True
+    names = {id(p): n for n, p in m.named_parameters()}
+    got = [{"attrs": {k: v for k, v in g.items() if k != "params"}, "params": [names[id(p)] for p in g["params"]]}
+           for g in U.get_param_groups(m)]
+    assert got == want["groups"]
+    assert abs(U.count_params(m) - want["count_params_M"]) < 1e-9 and abs(U.count_params(m, trainable=False) - want["count_all_M"]) < 1e-9
+
+
+def test_model_ema_matches_reference_class():
+    """tests/golden/model_ema.json (make_golden_ema.py): the reference's own ModelEMA after three updates of a bf16 toy network -
+    f32 averages of the trainable parameters, frozen ones untouched. Same scenario on the mirror class."""
+    import json
+
+    from diffnext.engine.engine_utils import ModelEMA
+
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "model_ema.json")))
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.LayerNorm(3)).to(torch.bfloat16)
+    net[1].bias.requires_grad = False
+    ema = ModelEMA(net, decay=0.9, update_every=2)
+    g = torch.Generator().manual_seed(4)
+    for _ in range(3):
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(torch.randn(p.shape, generator=g).to(p.dtype) * 0.1)
+        ema.update(net)
+    sd = ema.model.state_dict()
+    assert [str(v.dtype) for v in sd.values()] == want["dtypes"]
+    for k, v in sd.items():
+        assert v.float().flatten().tolist() == want["values"][k], k
+    assert ema.update_every == 2 and all(not p.requires_grad for p in ema.model.parameters())
+
+
 class FixedBatch(object):
     def __init__(self, seed=3, B=4):
         from diffnext.engine.datasets import SyntheticPointClouds
