@@ -205,6 +205,10 @@ typedef struct {
  * fused QKV projection on fp8 operands with the RoPE / q-scale epilogue of nova_qkv_rope (bf16 result). */
 int nova_row_norm_fp8(const void* in, void* out, const float* gamma, const float* beta, const void* res, void* out8, float* out8_scale,
                       long rows, int D, float eps, void* stream);
+/* out8[M,N] (e4m3 bytes) = saturate(GELU((A8 . W8^T) * a_scale[m] * w_scale[n] + bias) / *out_scale), and *out_amax raised
+ * (atomic max on the float's bits) to the largest |GELU(.)|: the fc1 of the fp8 stack under delayed scaling. */
+int nova_gemm_fp8_gelu_q8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const float* bias, void* out8,
+                          int M, int N, int K, const float* out_scale, unsigned* out_amax, void* stream);
 int nova_qkv_rope_fp8(const void* x8, const float* x_scale, const void* w8, const float* w_scale, const float* bias, const float* rope,
                       void* qkv, int S, int L, int D, int heads, int rope_batch, float q_scale, void* stream);
 
@@ -214,10 +218,16 @@ int nova_qkv_rope_fp8(const void* x8, const float* x_scale, const void* w8, cons
  * attention, its out-projection, the LayerNorms and the residual stream are as in the bf16 stack. `blocks` supplies the
  * biases, norms and the bf16 out-projection, `q` the fp8 weights. bf16 activations only. The reference has no fp8 path:
  * results are compared with the bf16 stack (tests), not with the reference. Extra workspaces: ws_x8 [S*L, D] bytes,
- * ws_xs [S*L] f32, ws_h8 [S*L, hidden] bytes, ws_hs [S*L] f32. Needs D, hidden % 256 == 0 and L >= 16. */
+ * ws_xs [S*L] f32, ws_h8 [S*L, hidden] bytes, ws_hs [S*L] f32. Needs D, hidden % 256 == 0 and L >= 16.
+ * h_scale / h_amax: both NULL (the MLP hidden rows are quantised per row by a pass between fc1 and fc2), or device arrays of
+ * nblocks floats / unsigned ("delayed scaling"): fc1's epilogue writes GELU(.) / h_scale[i] as e4m3 itself, saturated at +-448,
+ * and raises h_amax[i] (float bits, atomic max) to the largest |GELU(.)| it saw; fc2 uses h_scale[i] for every row. The
+ * caller zeroes h_amax and sets h_scale[i] = margin * amax_i / 448 from the PREVIOUS call of the same stack (first call: a
+ * guess) - NovaEngine does, per lane. */
 int nova_vit_blocks_forward_fp8(const nova_vit_block* blocks, const nova_vit_block_fp8* q, int nblocks, void* x, int S, int L, int D,
                                 int heads, int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
-                                void* ws_h, void* ws_x8, float* ws_xs, void* ws_h8, float* ws_hs, void* stream);
+                                void* ws_h, void* ws_x8, float* ws_xs, void* ws_h8, float* ws_hs, float* h_scale, unsigned* h_amax,
+                                void* stream);
 
 /* The same block stack for the conditioning encoder of multi-frame generation (max_latent_length > 1): the k | v rows
  * each block's fused QKV projection produces for the L rows of x are appended to that block's cache and attention runs

@@ -312,6 +312,13 @@ int nova_row_norm_fp8(const void* in, void* out, const float* gamma, const float
   return row_norm(a, NOVA_BF16, (hipStream_t)stream);
 }
 
+int nova_gemm_fp8_gelu_q8(const void* A8, const float* a_scale, const void* W8, const float* w_scale, const float* bias, void* out8,
+                          int M, int N, int K, const float* out_scale, unsigned* out_amax, void* stream) {
+  NOVA_REQUIRE(M <= 0 || (A8 && a_scale && W8 && w_scale && out8 && out_scale && out_amax), NOVA_ERR_ARG, "gemm_fp8_gelu_q8: null pointer");
+  return gemm256_fp8_launch(A8, a_scale, W8, w_scale, bias, out8, M, N, K, NOVA_EPI_GELU_Q8, (hipStream_t)stream, nullptr, 1, 1, 2, 0, 1.0f,
+                            0, 0, out_scale, out_amax);
+}
+
 int nova_qkv_rope_fp8(const void* x8, const float* x_scale, const void* w8, const float* w_scale, const float* bias, const float* rope,
                       void* qkv, int S, int L, int D, int heads, int rope_batch, float q_scale, void* stream) {
   NOVA_REQUIRE(S * L == 0 || (x8 && x_scale && w8 && w_scale && qkv), NOVA_ERR_ARG, "qkv_rope_fp8: null pointer");
@@ -326,9 +333,11 @@ int nova_qkv_rope_fp8(const void* x8, const float* x_scale, const void* w8, cons
 // one quantisation pass. Attention, its out-projection, LayerNorm statistics and the residual stream stay bf16 / f32.
 int nova_vit_blocks_forward_fp8(const nova_vit_block* blocks, const nova_vit_block_fp8* q, int nblocks, void* x, int S, int L, int D,
                                 int heads, int hidden, const float* rope, int rope_batch, void* ws_qkv, void* ws_a, void* ws_b,
-                                void* ws_h, void* ws_x8, float* ws_xs, void* ws_h8, float* ws_hs, void* stream) {
+                                void* ws_h, void* ws_x8, float* ws_xs, void* ws_h8, float* ws_hs, float* h_scale, unsigned* h_amax,
+                                void* stream) {
   NOVA_REQUIRE(nblocks == 0 || (blocks && q && x && ws_qkv && ws_a && ws_b && ws_h && ws_x8 && ws_xs && ws_h8 && ws_hs), NOVA_ERR_ARG,
                "vit_blocks_fp8: null pointer");
+  NOVA_REQUIRE((h_scale == nullptr) == (h_amax == nullptr), NOVA_ERR_ARG, "vit_blocks_fp8: h_scale and h_amax come together");
   NOVA_REQUIRE(heads > 0 && D % heads == 0, NOVA_ERR_SHAPE, "vit_blocks_fp8: D %% heads != 0");
   NOVA_REQUIRE(D % 256 == 0 && hidden % 256 == 0, NOVA_ERR_SHAPE, "vit_blocks_fp8: D and hidden must be multiples of 256");
   NOVA_REQUIRE(!rope || L >= 16, NOVA_ERR_SHAPE, "vit_blocks_fp8: L >= 16 with RoPE");
@@ -360,10 +369,20 @@ int nova_vit_blocks_forward_fp8(const nova_vit_block* blocks, const nova_vit_blo
     walk.next();
     NOVA_TRY(row_norm(n1, NOVA_BF16, st));
     walk.next();
-    NOVA_TRY(gemm256_fp8_launch(ws_x8, ws_xs, w.fc1_w8, w.fc1_ws, b.fc1_b, ws_h, M, hidden, D, NOVA_ACT_GELU_ERF, st));
-    NOVA_TRY(quantize_rows_fp8(ws_h, ws_h8, ws_hs, M, hidden, st));
-    walk.next();
-    NOVA_TRY(gemm256_fp8_launch(ws_h8, ws_hs, w.fc2_w8, w.fc2_ws, b.fc2_b, ws_b, M, D, hidden, NOVA_ACT_NONE, st));
+    if (h_scale) {
+      // delayed scaling: fc1 writes GELU(.) / h_scale[i] as e4m3 itself and records max |GELU(.)| in h_amax[i], from which the
+      // caller sets the scale of the next call; fc2 reads one scale for all rows
+      NOVA_TRY(gemm256_fp8_launch(ws_x8, ws_xs, w.fc1_w8, w.fc1_ws, b.fc1_b, ws_h8, M, hidden, D, NOVA_EPI_GELU_Q8, st, nullptr, 1, 1, 2, 0,
+                                  1.0f, 0, 0, h_scale + i, h_amax + i));
+      walk.next();
+      NOVA_TRY(gemm256_fp8_launch(ws_h8, h_scale + i, w.fc2_w8, w.fc2_ws, b.fc2_b, ws_b, M, D, hidden, NOVA_ACT_NONE, st, nullptr, 1, 1, 2, 0,
+                                  1.0f, 0, 1));
+    } else {
+      NOVA_TRY(gemm256_fp8_launch(ws_x8, ws_xs, w.fc1_w8, w.fc1_ws, b.fc1_b, ws_h, M, hidden, D, NOVA_ACT_GELU_ERF, st));
+      NOVA_TRY(quantize_rows_fp8(ws_h, ws_h8, ws_hs, M, hidden, st));
+      walk.next();
+      NOVA_TRY(gemm256_fp8_launch(ws_h8, ws_hs, w.fc2_w8, w.fc2_ws, b.fc2_b, ws_b, M, D, hidden, NOVA_ACT_NONE, st));
+    }
     RowNormArgs n2{ws_b, x, b.norm2_w, b.norm2_b, nullptr, 0, -1, -1, -1, x, nullptr, M, D, 1e-5f};
     if (i + 1 < nblocks) {  // the next block's QKV input
       n2.out8 = ws_x8;

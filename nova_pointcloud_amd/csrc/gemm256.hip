@@ -46,9 +46,15 @@ struct GemmEpi256 {
   const float* sa;  // fp8 path: per-row dequantisation scale of A [M]
   const float* sw;  // fp8 path: per-row (output column) dequantisation scale of W [N]
   int stagger;  // persistent form: start delay of the last workgroup in cycles (0 = none), see gemm256p_kernel
+  int sa_scalar = 0;            // fp8 path: sa points at ONE scale shared by all rows of A (a tensor quantised with a static scale)
+  const float* q8_scale = nullptr;  // E_GELU_Q8: the scale the e4m3 output is quantised with (one float, read at kernel entry)
+  unsigned* q8_amax = nullptr;      // E_GELU_Q8: running max |value| of the un-quantised outputs, as float bits (atomic max)
 };
 
-enum { E_NONE = 0, E_GELU = 1, E_SILU = 2, E_ROPE = 3 };
+// E_GELU_Q8 (fp8 operands only): GELU, then the result is written as OCP e4m3 bytes, value / *q8_scale saturated at +-448,
+// instead of bf16 - the A operand of the next fp8 GEMM without a quantisation pass ("delayed scaling": the caller derives
+// the next call's scale from q8_amax).
+enum { E_NONE = 0, E_GELU = 1, E_SILU = 2, E_ROPE = 3, E_GELU_Q8 = 5 };
 
 template <typename T> struct PFrag;
 template <> struct PFrag<bf16_t> { bf8v v; };
@@ -317,7 +323,10 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
                                                           int ntm, int ntn, GemmEpi256 e) {
   typedef typename OutOf<T>::type OT;
   constexpr bool FP8 = sizeof(T) == 1;
-  constexpr int STORES_TILE = sizeof(OT) == 2 ? 16 : 32;  // global stores a wave issues per tile epilogue
+  constexpr bool Q8 = EPI == E_GELU_Q8;
+  // vector-memory operations a wave issues per tile epilogue behind the next tile's prologue DMAs (exact: the wait at the next
+  // tile top counts them): 16-byte stores of bf16 / f32 results; e4m3 results: 8 stores + 1 atomic max
+  constexpr int STORES_TILE = Q8 ? 9 : (sizeof(OT) == 2 ? 16 : 32);
   __shared__ __attribute__((aligned(16))) char smem[P_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
         bfv[nf] = e.bias ? *reinterpret_cast<const f4v*>(e.bias + cn0 + wc * 64 + nf * 16 + fg * 4) : f4v{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int mf = 0; mf < 8; ++mf) sav[mf] = e.sa[min(cm0 + wr * 128 + mf * 16 + fr, M - 1)];
+      for (int mf = 0; mf < 8; ++mf) sav[mf] = e.sa[e.sa_scalar ? 0 : min(cm0 + wr * 128 + mf * 16 + fr, M - 1)];
       asm volatile("" ::"v"(sav[7]));  // youngest of them: the compiler's wait sits here (loads retire in order)
       // dequantise in place, ahead of everything else: the three scale / bias vectors (40 registers) are dead before the
       // epilogue proper starts to load its RoPE rows (kept live through it they cost the RoPE variant 97 spilled VGPRs)
@@ -542,6 +551,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
         for (int nf = 0; nf < 4; ++nf) cs[g][j][nf] = *reinterpret_cast<const f4v*>(ropem + coff[nf]);
       }
     };
+    float q8_inv = 1.0f, q8_max = 0.f;
+    if constexpr (Q8) q8_inv = 1.0f / *e.q8_scale;
     auto finish_group = [&](int g, auto rotated) {
       constexpr bool ROT = decltype(rotated)::value;
 #pragma unroll
@@ -550,6 +561,32 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
         // rows past M were staged as copies of row M-1, so their lanes hold row M-1's results and store the identical
         // bytes there again: no branch, and every tile issues the same number of stores (the vmcnt count above)
         const int m = min(cm0 + wr * 128 + mf * 16 + fr, M - 1);
+        if constexpr (Q8) {
+          uint32_t d[4];  // this lane's 4 columns of every 16-column fragment as 4 e4m3 bytes
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) {
+            f4v v = acc[nf][mf];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q] = gelu_erf_fast(v[q]);
+              q8_max = fmaxf(q8_max, fabsf(v[q]));
+              v[q] = __builtin_amdgcn_fmed3f(v[q] * q8_inv, -448.0f, 448.0f);
+            }
+            int w = 0;
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
+            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
+            d[nf] = (uint32_t)w;
+          }
+          // 4 x 4 transpose of dwords between the wave's four 16-lane rows (fg) and the four fragments (nf): afterwards the
+          // lane in row fg holds fragment nf = fg's columns 0..15 of its matrix row = 16 contiguous bytes, one 16-byte store
+          const auto s01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
+          const auto s23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
+          const auto sac = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+          const auto sbd = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+          u4v o = {sac[0], sbd[0], sac[1], sbd[1]};
+          *reinterpret_cast<u4v*>(reinterpret_cast<uint8_t*>(C) + (size_t)m * N + cn0 + wc * 64 + fg * 16) = o;
+          continue;
+        }
         u2v pk[4];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
@@ -620,6 +657,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
       finish_group(1, std::false_type{});
       finish_group(2, std::false_type{});
       finish_group(3, std::false_type{});
+    }
+    if constexpr (Q8) {  // one atomic max per wave and tile (values are >= 0: float order == unsigned order of the bits)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) q8_max = fmaxf(q8_max, __shfl_xor(q8_max, o, 64));
+      if (fresh_lane() == 0) __hip_atomic_fetch_max(e.q8_amax, __float_as_uint(q8_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!more) break;
     first = false;
@@ -700,16 +742,20 @@ static int launch256p(const void* A, const void* W, void* C, int M, int N, int K
 // q_scale on the first q_cols columns), applied after the dequantisation scales and the bias.
 int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, void* C, int M,
                        int N, int K, int epi, hipStream_t st, const float* rope, int L, int rope_batch, int hd, int rope_cols,
-                       float q_scale, int q_cols) {
+                       float q_scale, int q_cols, int sa_scalar, const float* q8_scale, unsigned* q8_amax) {
   if (M <= 0) return 0;
   if (N % 256 != 0 || K % 128 != 0 || K <= 0) return set_error(NOVA_ERR_SHAPE, "gemm_fp8: need N %% 256 == 0 and K %% 128 == 0 (got N=%d K=%d)", N, K);
   if (epi == E_ROPE && (rope_cols % 256 || q_cols % 256 || (rope && (L < 16 || rope_batch <= 0 || hd <= 0))))
     return set_error(NOVA_ERR_SHAPE, "gemm_fp8: RoPE epilogue needs rope_cols, q_cols %% 256 == 0 and L >= 16");
   GemmEpi256 e{bias, rope, rope ? L : 1, rope ? rope_batch : 1, rope ? hd : 2, rope ? rope_cols : 0, q_scale, q_cols, g_gm256,
                walk_is_reverse() ? 1 : 0, sa, sw, 0};
+  e.sa_scalar = sa_scalar;
+  e.q8_scale = q8_scale;
+  e.q8_amax = q8_amax;
+  if (epi == E_GELU_Q8 && (!q8_scale || !q8_amax)) return set_error(NOVA_ERR_ARG, "gemm_fp8: the e4m3-output epilogue needs a scale and an amax word");
   const int ntm = (M + 255) / 256, ntn = N / 256;
   dim3 grid(cu_slots()), block(512);
-  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  ProfScope prof(PROF_GEMM_NONE + (epi == E_GELU_Q8 ? E_GELU : epi), 2.0 * M * N * K, st);
   const fp8_t* a = static_cast<const fp8_t*>(A8);
   const fp8_t* w = static_cast<const fp8_t*>(W8);
   bf16_t* c = static_cast<bf16_t*>(C);
@@ -718,6 +764,7 @@ int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const fl
     case E_GELU: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     case E_SILU: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     case E_ROPE: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_GELU_Q8: hipLaunchKernelGGL((gemm256p_kernel<fp8_t, E_GELU_Q8>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     default: return set_error(NOVA_ERR_ARG, "gemm_fp8: unknown epilogue %d", epi);
   }
   return check_launch("gemm256p fp8");

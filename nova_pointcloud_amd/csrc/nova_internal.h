@@ -73,7 +73,9 @@ int scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B,
 int quantize_rows_fp8(const void* x, void* out, float* scale, long rows, int D, hipStream_t st);
 int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const float* sw, const float* bias, void* C, int M,
                        int N, int K, int epi, hipStream_t st, const float* rope = nullptr, int L = 1, int rope_batch = 1,
-                       int hd = 2, int rope_cols = 0, float q_scale = 1.0f, int q_cols = 0);
+                       int hd = 2, int rope_cols = 0, float q_scale = 1.0f, int q_cols = 0, int sa_scalar = 0,
+                       const float* q8_scale = nullptr, unsigned* q8_amax = nullptr);
+constexpr int NOVA_EPI_GELU_Q8 = 5;  // gemm256.hip E_GELU_Q8: GELU + e4m3 output with a static scale (fp8 operands only)
 int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, hipStream_t st);
 int silu_add_steps(const void* a, const void* vecs, void* out, long rows, int nvec, int D, int dtype, hipStream_t st);
 int timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, hipStream_t st);

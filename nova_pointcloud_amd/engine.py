@@ -177,6 +177,7 @@ class NovaEngine(object):
         self.model = model
         self.sig = None
         self.fp8 = False
+        self.fp8_delayed = True
         self.ws_key, self.ws = None, {}
 
     # ------------------------------------------------------------------ packing / workspaces
@@ -267,9 +268,22 @@ class NovaEngine(object):
             q = pack.__dict__.get("fp8")
             if q is None:
                 q = pack.fp8 = pack_vit_blocks_fp8(pack.modules)
+            # delayed scaling of the MLP hidden rows (per lane and stack): the scale of this call comes from the largest |GELU|
+            # the previous call of the same stack saw (x 2 headroom; e4m3 saturates beyond); the first call guesses 64 / 448
+            state = ws.setdefault("q8", {}).get(id(pack))
+            if state is None and self.fp8_delayed:
+                n = len(pack.arr)
+                state = ws["q8"][id(pack)] = (torch.full((n,), 64.0 / 448.0, dtype=_F32, device=self.dev),
+                                              torch.zeros(n, dtype=torch.int32, device=self.dev))
+            sc, am = state if self.fp8_delayed else (None, None)
             hip.call("nova_vit_blocks_forward_fp8", pack.arr, q.arr, len(pack.arr), x.data_ptr(), S, L, self.D, self.heads, self.hidden,
                      hip.ptr(rope), rope_batch, ws["qkv"].data_ptr(), ws["a"].data_ptr(), ws["b"].data_ptr(), ws["h"].data_ptr(),
-                     ws["x8"].data_ptr(), ws["xs"].data_ptr(), ws["h8"].data_ptr(), ws["hs"].data_ptr(), hip.stream_ptr())
+                     ws["x8"].data_ptr(), ws["xs"].data_ptr(), ws["h8"].data_ptr(), ws["hs"].data_ptr(), hip.ptr(sc), hip.ptr(am),
+                     hip.stream_ptr())
+            if sc is not None:
+                seen = am.view(_F32)
+                torch.where(seen > 0, seen * (2.0 / 448.0), sc, out=sc)
+                am.zero_()
             return
         hip.call("nova_vit_blocks_forward", pack.arr, len(pack.arr), x.data_ptr(), S, L, self.D, self.heads, self.hidden,
                  hip.ptr(rope), rope_batch, ws["qkv"].data_ptr(), ws["a"].data_ptr(), ws["b"].data_ptr(),
@@ -346,6 +360,7 @@ class NovaEngine(object):
         if gemm_dtype not in (None, "bf16", "fp8"):
             raise ValueError(f"gemm_dtype {gemm_dtype!r}: the encoder GEMMs run in the model dtype or in 'fp8'")
         self.fp8 = gemm_dtype == "fp8"
+        self.fp8_delayed = not inputs.get("fp8_row_scaled_hidden", False)  # False: per-row quantisation pass between fc1 and fc2
         if self.fp8 and (self.dtype != torch.bfloat16 or self.D % 256 or self.hidden % 256):
             raise NotImplementedError("gemm_dtype='fp8' needs a bfloat16 model whose width and MLP width are multiples of 256")
         with torch.cuda.device(self.dev):  # launches go to the model's device whatever the caller's current device is

@@ -80,9 +80,10 @@ SIGNATURES = {
     "nova_vit_blocks_forward": [ctypes.POINTER(VitBlock), c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_int]
     + [c_void_p] * 4 + [c_int, c_void_p],
     "nova_row_norm_fp8": [c_void_p] * 7 + [c_long, c_int, c_float, c_void_p],
+    "nova_gemm_fp8_gelu_q8": [c_void_p] * 6 + [c_int] * 3 + [c_void_p, c_void_p, c_void_p],
     "nova_qkv_rope_fp8": [c_void_p] * 7 + [c_int] * 5 + [c_float, c_void_p],
     "nova_vit_blocks_forward_fp8": [ctypes.POINTER(VitBlock), ctypes.POINTER(VitBlockFp8), c_int, c_void_p] + [c_int] * 5
-    + [c_void_p, c_int] + [c_void_p] * 8 + [c_void_p],
+    + [c_void_p, c_int] + [c_void_p] * 10 + [c_void_p],
     "nova_vit_blocks_forward_kv": [ctypes.POINTER(VitBlock), c_int, c_void_p] + [c_int] * 5 + [c_void_p, c_int]
     + [c_void_p, c_long, c_long] + [c_void_p] * 4 + [c_int, c_void_p],
     "nova_pointset_nn_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_int, c_void_p],

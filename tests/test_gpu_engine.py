@@ -435,6 +435,10 @@ def test_fp8_gemm_mode_small_model(hip):
     b = pipe(gemm_dtype="fp8", **kw).frames.float()
     assert torch.isfinite(b).all() and not torch.equal(a, b)
     assert rms_rel(b, a) < 0.2
+    c = pipe(gemm_dtype="fp8", fp8_row_scaled_hidden=True, **kw).frames.float()  # per-row quantisation pass instead of delayed scaling
+    assert torch.isfinite(c).all() and rms_rel(c, a) < 0.2 and rms_rel(c, b) < 0.2
+    b2 = pipe(gemm_dtype="fp8", **kw).frames.float()  # second call: the scales now come from the first call's amax
+    assert torch.isfinite(b2).all() and rms_rel(b2, a) < 0.2
     with pytest.raises(ValueError):
         pipe(gemm_dtype="int4", **kw)
     with pytest.raises(NotImplementedError):

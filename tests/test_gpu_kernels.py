@@ -424,3 +424,27 @@ def test_gemm_fp8_qkv_rope_epilogue(hip):
         rot[:, :, t, ..., 0], rot[:, :, t, ..., 1] = a * c - b * s_, a * s_ + b * c
     rot[:, :, 0] *= 0.5  # q_scale on the q third
     assert relerr(out, rot.reshape(S * L, 3 * D).float()) < tol(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (700, 512, 384), (5000, 1536, 1024)])
+def test_gemm_fp8_gelu_with_e4m3_output(hip, M, N, K):
+    """fc1 of the fp8 stack under delayed scaling: GELU then e4m3 bytes with a static scale straight from the epilogue (4 x 4
+    lane-row transpose into 16-byte stores), the running |max| recorded. Against the dequantised product: every element within
+    e4m3's half-ulp (2^-4 relative, plus the subnormal step), so a misplaced byte or column would show; saturation at +-448."""
+    a, w = rnd(M, K, dtype=torch.bfloat16, seed=101), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=102)
+    bias = rnd(N, seed=103)
+    a8, sa = hip.quantize_rows_fp8(a)
+    w8, sw = hip.quantize_rows_fp8(w)
+    ref = torch.nn.functional.gelu(_dequant(a8, sa).double() @ _dequant(w8, sw).double().T + bias.double()).float()
+    for scale_val in (float(ref.abs().max()) * 1.5 / 448.0, float(ref.abs().max()) * 0.25 / 448.0):  # in range / saturating
+        scale = torch.tensor([scale_val], device=DEV)
+        amax = torch.zeros(1, dtype=torch.int32, device=DEV)
+        out8 = torch.empty(M, N, dtype=torch.uint8, device=DEV)
+        hip.call("nova_gemm_fp8_gelu_q8", a8.data_ptr(), sa.data_ptr(), w8.data_ptr(), sw.data_ptr(), bias.data_ptr(), out8.data_ptr(),
+                 M, N, K, scale.data_ptr(), amax.data_ptr(), hip.stream_ptr())
+        got = out8.view(torch.float8_e4m3fn).float() * scale_val
+        want = ref.clamp(-448 * scale_val, 448 * scale_val)
+        err = (got - want).abs()
+        assert bool((err <= want.abs() * 2.0 ** -4 + scale_val * 2.0 ** -9 + 1e-4).all()), float((err - want.abs() * 2.0 ** -4).max())
+        seen = float(amax.view(torch.float32))
+        assert abs(seen - float(ref.abs().max())) <= 1e-3 * float(ref.abs().max())
