@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NOVA_HIP_VERSION 200 /* 0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows */
+#define NOVA_HIP_VERSION 201 /* 0.2.1: nova_adaln_fc1 (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
 
 typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1 } nova_dtype;
 typedef enum { NOVA_ACT_NONE = 0, NOVA_ACT_GELU_ERF = 1, NOVA_ACT_SILU = 2 } nova_act;
@@ -55,10 +55,17 @@ int nova_check_device(void);
 int nova_prof_enable(int on);
 int nova_prof_collect(double* ms, double* work, long long* launches, int slots);
 
-/* Test hook: 0 = automatic choice between the 128x128 and the 256x256 (large-M) GEMM structures,
- * 128 / 256 = force one, 257 = the 256 structure in its one-tile-per-workgroup form (the fallback of the persistent
- * kernel); all compute bit-identical results (tests/test_gpu_kernels.py compares them). */
+/* Test hook: 0 = automatic choice between the GEMM structures by shape, 16 = the small-M whole-K kernel (bf16, K 768 /
+ * 1024; an error for other shapes), 128 / 256 = force the 128x128 or the 256x256 (large-M, persistent) structure,
+ * 257 = the 256 structure in its one-tile-per-workgroup form (the fallback of the persistent kernel); all compute
+ * bit-identical results (tests/test_gpu_kernels.py compares them). Per calling thread. */
 int nova_debug_force_gemm_tile(int tile);
+
+/* nova_decoder_denoise replays its launch sequence as a hipGraph, captured once per distinct argument set (on by
+ * default; environment NOVA_GRAPHS=0 or on = 0 here switches to direct launches and drops the cached graphs of the
+ * calling thread). Results are identical either way. Stats: graphs captured / replayed by the calling thread. */
+int nova_debug_set_graphs(int on);
+int nova_debug_graph_stats(long* captures, long* replays);
 
 /* ---- projection GEMM -----------------------------------------------------------------------
  * out[M,N] = act(A[M,K] * W[N,K]^T + bias[N])        W in nn.Linear layout.
@@ -121,6 +128,15 @@ int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, i
 int nova_row_norm(const void* in, void* out, const float* gamma, const float* beta, const void* mod, long mod_ld,
                   int scale_off, int shift_off, int gate_off, const void* res, const int* gather, long rows, int D,
                   float eps, int dtype, void* stream);
+
+/* out = act(h W^T + bias) with h = LN(x)(1 + mod[:, scale_off:+D]) + mod[:, shift_off:+D], LN without affine: the first
+ * half of DiffusionBlock.forward, `self.proj(self.norm1(x, z)...)` up to the activation (diffusion_mlp.py:41-47 with
+ * AdaLayerNormZero normalization.py:34-36 and the Projector's fc1 + SiLU diffusion_mlp.py:31-36). For bf16 rows of width
+ * 768 / 1024 and a few hundred rows (the per-step launches of the denoising loop at small batch) this is ONE launch with
+ * the modulate as the GEMM's prologue; otherwise it runs as nova_row_norm into `h` followed by nova_gemm_bias_act, and
+ * both forms give bit-identical `out`. `h` [rows, D] is scratch (written only by the two-launch form). */
+int nova_adaln_fc1(const void* x, const void* mod, long mod_ld, int scale_off, int shift_off, float eps, const void* w,
+                   const float* bias, void* h, void* out, long rows, int N, int D, int act, int dtype, void* stream);
 
 /* ---- token plumbing of the masked-autoregressive encoder ------------------------------------
  * z0 = MaskEmbed(PatchEmbed(canvas)) (+ abs-PE): embeddings.py:160-166,272-274,90-91.

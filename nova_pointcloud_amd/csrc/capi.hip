@@ -5,7 +5,10 @@
 #include <cstring>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
+#include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 #include "common.h"
@@ -107,7 +110,7 @@ int nova_check_device(void) {
 
 int nova_debug_force_gemm_tile(int tile) {
   NOVA_REQUIRE(gemm_force_tile(tile) == 0, NOVA_ERR_ARG,
-               "force_gemm_tile: this build knows 0 (auto), 128, 256 (persistent) and 257 (one tile per workgroup); experiment codes need the NOVA_EXPERIMENTS build");
+               "force_gemm_tile: this build knows 0 (auto), 16 (small-M kernel), 128, 256 (persistent) and 257 (one tile per workgroup); experiment codes need the NOVA_EXPERIMENTS build");
   return 0;
 }
 
@@ -190,6 +193,15 @@ int nova_row_norm(const void* in, void* out, const float* gamma, const float* be
   NOVA_REQUIRE(rows == 0 || (in && out), NOVA_ERR_ARG, "row_norm: null pointer");
   RowNormArgs a{in, out, gamma, beta, mod, mod_ld, scale_off, shift_off, gate_off, res, gather, rows, D, eps};
   return row_norm(a, dtype, (hipStream_t)stream);
+}
+
+int nova_adaln_fc1(const void* x, const void* mod, long mod_ld, int scale_off, int shift_off, float eps, const void* w,
+                   const float* bias, void* h, void* out, long rows, int N, int D, int act, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "adaln_fc1: bad dtype %d", dtype);
+  NOVA_REQUIRE(rows == 0 || (x && mod && w && h && out), NOVA_ERR_ARG, "adaln_fc1: null pointer");
+  NOVA_REQUIRE(rows >= 0 && rows <= 0x7fffffffL && scale_off >= 0 && shift_off >= 0, NOVA_ERR_ARG, "adaln_fc1: bad rows / offsets");
+  RowNormArgs m{x, h, nullptr, nullptr, mod, mod_ld, scale_off, shift_off, -1, nullptr, nullptr, rows, D, eps};
+  return gemm_modulate_act(m, w, bias, out, (int)rows, N, D, act, dtype, (hipStream_t)stream);
 }
 
 int nova_embed_canvas(const float* canvas, const float* mask, const void* w, const float* bias, const void* mask_token,
@@ -426,18 +438,16 @@ int nova_modulate_rows(const void* x, const void* mod, void* out, long rows, int
   return modulate_rows(x, mod, out, rows, D, dtype, (hipStream_t)stream);
 }
 
-int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
-                         const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
-                         void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int mod_steps,
-                         int dtype, void* stream) {
-  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "decoder_denoise: bad dtype %d", dtype);
-  NOVA_REQUIRE(dec && zc && temb && x && sched && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
-               "decoder_denoise: null pointer");
-  NOVA_REQUIRE(S == B || S == 2 * B || S == 3 * B, NOVA_ERR_SHAPE, "decoder_denoise: S must be B, 2B or 3B");
+}  // extern "C"
+
+namespace nova {
+
+// The launch sequence of one AR step's denoising loop (called directly, or once under stream capture: see below).
+static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
+                                    const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
+                                    void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int mod_steps,
+                                    int dtype, hipStream_t st) {
   const bool do_renorm = renorm < 1.0f;
-  NOVA_REQUIRE(!do_renorm || (echo_energy && ws_v), NOVA_ERR_ARG, "decoder_denoise: renorm needs echo_energy and ws_v");
-  if (n == 0 || B == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
   const size_t es = esize(dtype);
   const int depth = dec->depth;
   const long mod_ld = (long)(3 * depth + 2) * D;
@@ -474,8 +484,7 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
     for (int b = 0; b < depth; ++b) {
       const nova_mlp_block& blk = dec->blocks[b];
       RowNormArgs m1{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, b * 3 * D, b * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
-      NOVA_TRY(row_norm(m1, dtype, st));
-      NOVA_TRY(gemm_bias_act(ws_h, blk.fc1_w, blk.fc1_b, ws_f, (int)rows, D, D, NOVA_ACT_SILU, dtype, st));
+      NOVA_TRY(gemm_modulate_act(m1, blk.fc1_w, blk.fc1_b, ws_f, (int)rows, D, D, NOVA_ACT_SILU, dtype, st));  // one launch at small M
       NOVA_TRY(gemm_bias_act(ws_f, blk.fc2_w, blk.fc2_b, ws_g, (int)rows, D, D, NOVA_ACT_NONE, dtype, st));
       RowNormArgs m2{ws_g, ws_u, blk.norm2_w, blk.norm2_b, ws_mod, mod_ld, -1, -1, b * 3 * D + 2 * D, ws_u, nullptr, rows, D, 1e-5f};
       NOVA_TRY(row_norm(m2, dtype, st));
@@ -493,6 +502,112 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
       if (do_renorm && echo_energy) NOVA_TRY(scale_vector(echo_energy, B, (1.0f + sp.c0) * (1.0f + sp.c0), st));
     }
   }
+  return 0;
+}
+
+
+// ---- hipGraph replay of the denoising loop.
+// One AR step issues steps x (3 x depth + 3) = 25 x 21 launches of 4-15 us kernels; at small batch with two stream lanes
+// the single host thread (about 9 us per launch) cannot keep both streams fed and the step becomes launch-bound
+// (tools/host_vs_gpu.py, tools/trace_gaps.py). The sequence is a pure function of the call's arguments, so it is captured
+// once per distinct argument set - pointers, shapes, the per-step sampler plan and the decoder's weight pointers all
+// go into the key - and replayed with one hipGraphLaunch afterwards. The engine keeps every buffer of the call at a
+// stable address (workspace slots), so from the second generation on every AR step of a fixed schedule is a replay.
+// Calls that read per-call tensors the engine allocates afresh (ancestral noise, guidance-renorm scratch) and profiled
+// runs (HIP-event brackets around launches) stay on the direct path.
+struct DecoderGraphs {
+  std::unordered_map<std::string, hipGraphExec_t> execs;
+  long captures = 0, replays = 0;
+  ~DecoderGraphs() { clear(); }
+  void clear() {
+    for (auto& kv : execs) (void)hipGraphExecDestroy(kv.second);
+    execs.clear();
+  }
+};
+static thread_local DecoderGraphs g_dec_graphs;
+static std::atomic<int> g_graphs_on{-1};  // -1: not decided yet (NOVA_GRAPHS env, default on)
+
+static bool graphs_enabled() {
+  int v = g_graphs_on.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("NOVA_GRAPHS");
+    v = (e && e[0] == '0') ? 0 : 1;
+    g_graphs_on.store(v);
+  }
+  return v != 0;
+}
+
+template <typename T> static void key_put(std::string& k, const T& v) { k.append(reinterpret_cast<const char*>(&v), sizeof(T)); }
+
+}  // namespace nova
+
+extern "C" {
+
+int nova_debug_set_graphs(int on) {
+  g_graphs_on.store(on ? 1 : 0);
+  if (!on) g_dec_graphs.clear();
+  return 0;
+}
+
+int nova_debug_graph_stats(long* captures, long* replays) {
+  if (captures) *captures = g_dec_graphs.captures;
+  if (replays) *replays = g_dec_graphs.replays;
+  return 0;
+}
+
+int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
+                         const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
+                         void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int mod_steps,
+                         int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "decoder_denoise: bad dtype %d", dtype);
+  NOVA_REQUIRE(dec && zc && temb && x && sched && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
+               "decoder_denoise: null pointer");
+  NOVA_REQUIRE(S == B || S == 2 * B || S == 3 * B, NOVA_ERR_SHAPE, "decoder_denoise: S must be B, 2B or 3B");
+  const bool do_renorm = renorm < 1.0f;
+  NOVA_REQUIRE(!do_renorm || (echo_energy && ws_v), NOVA_ERR_ARG, "decoder_denoise: renorm needs echo_energy and ws_v");
+  if (n == 0 || B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool direct = !graphs_enabled() || g_prof_on.load(std::memory_order_relaxed) || noise != nullptr || do_renorm || steps < 2;
+  if (direct)
+    return decoder_denoise_launches(dec, zc, temb, x, sched, noise, renorm, echo_energy, steps, S, B, n, P, D, ws_a, ws_u, ws_h, ws_f,
+                                    ws_g, ws_mod, ws_v, mod_steps, dtype, st);
+  std::string key;
+  key.reserve(512 + sizeof(nova_sampler_step) * steps + sizeof(nova_mlp_block) * dec->depth);
+  key_put(key, *dec);
+  for (int b = 0; b < dec->depth; ++b) key_put(key, dec->blocks[b]);
+  for (int i = 0; i < steps; ++i) key_put(key, sched[i]);
+  const void* ptrs[] = {zc, temb, x, ws_a, ws_u, ws_h, ws_f, ws_g, ws_mod, (const void*)st};
+  key_put(key, ptrs);
+  const int ints[] = {steps, S, B, n, P, D, mod_steps, dtype, walk_is_reverse() ? 1 : 0, gemm_forced_tile()};
+  key_put(key, ints);
+  auto it = g_dec_graphs.execs.find(key);
+  if (it == g_dec_graphs.execs.end()) {
+    if (g_dec_graphs.execs.size() >= 2048) g_dec_graphs.clear();  // schedules come and go: start over rather than grow
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      return decoder_denoise_launches(dec, zc, temb, x, sched, noise, renorm, echo_energy, steps, S, B, n, P, D, ws_a, ws_u, ws_h, ws_f,
+                                      ws_g, ws_mod, ws_v, mod_steps, dtype, st);
+    }
+    const int rc = decoder_denoise_launches(dec, zc, temb, x, sched, noise, renorm, echo_energy, steps, S, B, n, P, D, ws_a, ws_u, ws_h,
+                                            ws_f, ws_g, ws_mod, ws_v, mod_steps, dtype, st);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(st, &graph);
+    if (rc != 0) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    NOVA_REQUIRE(ec == hipSuccess && graph, NOVA_ERR_LAUNCH, "decoder_denoise: stream capture failed: %s", hipGetErrorString(ec));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    NOVA_REQUIRE(ei == hipSuccess && exec, NOVA_ERR_LAUNCH, "decoder_denoise: hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    it = g_dec_graphs.execs.emplace(std::move(key), exec).first;
+    ++g_dec_graphs.captures;
+  } else {
+    ++g_dec_graphs.replays;
+  }
+  const hipError_t el = hipGraphLaunch(it->second, st);
+  NOVA_REQUIRE(el == hipSuccess, NOVA_ERR_LAUNCH, "decoder_denoise: hipGraphLaunch failed: %s", hipGetErrorString(el));
   return 0;
 }
 

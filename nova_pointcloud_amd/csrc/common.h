@@ -57,11 +57,26 @@ template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// Wave-wide sum / max, every lane ending with the same value, without the LDS crossbar: __shfl_xor compiles to
+// ds_bpermute_b32 (an LDS-pipe round trip per step, six steps); here four steps are DPP operands of the add itself
+// and the last two are the gfx950 row swaps. Each step pairs lane groups symmetrically (both partners compute
+// a + b), so all lanes agree bit for bit. Pairing: i <-> 7 - i (row_half_mirror), xor 1, xor 2 (quad_perm),
+// i <-> 15 - i (row_mirror), rows 0|1 and 2|3 (v_permlane16_swap), halves (v_permlane32_swap).
+template <int CTRL> __device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+template <typename F> __device__ __forceinline__ float wave_combine(float v, F f) {
+  v = f(v, dpp_move<0x141>(v));
+  v = f(v, dpp_move<0xb1>(v));
+  v = f(v, dpp_move<0x4e>(v));
+  v = f(v, dpp_move<0x140>(v));
+  const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = f(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+  const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return f(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_combine(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_combine(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // max over a lane and its partner lane ^ 32 without the LDS round trip of ds_bpermute: v_permlane32_swap of x with
 // itself leaves (x.lo, x.lo) and (x.hi, x.hi) in the two results

@@ -204,6 +204,7 @@ void gemm256_set_stagger(int cycles);
 void gemm256_set_grid(int n);
 void walk_set_alternate(int on);
 #endif
+int gemm_forced_tile() { return g_force_tile; }
 int gemm_force_tile(int tile) {
 #ifdef NOVA_EXPERIMENTS  // A/B knobs of tools/ (make exp): never compiled into the shipped library
   if (tile == 50000 || tile == 50001) {  // alternate the walk direction between launches of a block (off / on)
@@ -227,9 +228,9 @@ int gemm_force_tile(int tile) {
     tile = 256;
   }
 #endif
-  if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return -1;
-  g_force_tile = tile;  // 257: the 256 tile in its one-tile-per-workgroup form (the fallback of the persistent kernel)
-  return 0;
+  if (tile != 0 && tile != 16 && tile != 128 && tile != 256 && tile != 257) return -1;
+  g_force_tile = tile;  // 257: the 256 tile in its one-tile-per-workgroup form (the fallback of the persistent kernel);
+  return 0;             // 16: the small-M kernel of skinny.hip wherever its shapes allow (an error elsewhere)
 }
 
 template <typename T>
@@ -264,8 +265,18 @@ int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, in
                   int dtype, hipStream_t st) {
   GemmEpi e{bias, nullptr, 1, 1, 2, 0, 1.0f, 0};
   if (act < 0 || act > 2) return set_error(NOVA_ERR_ARG, "gemm: unknown activation %d", act);
+  if (dtype == NOVA_BF16 && (g_force_tile == 16 || (g_force_tile == 0 && skinny_gemm_fits(M, N, K, false))))
+    return skinny_gemm(A, W, bias, out, M, N, K, act, nullptr, st);
   return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(A, W, out, M, N, K, act, e, st)
                             : launch_gemm<float>(A, W, out, M, N, K, act, e, st);
+}
+
+int gemm_modulate_act(const RowNormArgs& pro, const void* W, const float* bias, void* out, int M, int N, int K, int act,
+                      int dtype, hipStream_t st) {
+  if (dtype == NOVA_BF16 && (g_force_tile == 16 || (g_force_tile == 0 && skinny_gemm_fits(M, N, K, true))))
+    return skinny_gemm(nullptr, W, bias, out, M, N, K, act, &pro, st);
+  if (int rc = row_norm(pro, dtype, st)) return rc;
+  return gemm_bias_act(pro.out, W, bias, out, M, N, K, act, dtype, st);
 }
 
 int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const float* rope, void* qkv, int S, int L,

@@ -659,8 +659,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
       finish_group(3, std::false_type{});
     }
     if constexpr (Q8) {  // one atomic max per wave and tile (values are >= 0: float order == unsigned order of the bits)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) q8_max = fmaxf(q8_max, __shfl_xor(q8_max, o, 64));
+      q8_max = wave_max(q8_max);
       if (fresh_lane() == 0) __hip_atomic_fetch_max(e.q8_amax, __float_as_uint(q8_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!more) break;

@@ -30,6 +30,7 @@ int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const floa
 int gemm_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
                    int L, int rope_batch, int hd, int rope_cols, int dtype, hipStream_t st);
 int gemm_force_tile(int tile);  // 0 on success, -1 for a value this build does not know
+int gemm_forced_tile();  // the calling thread's current setting (part of the decoder graph key)
 // traversal direction of the NEXT launches of the row-tiled kernels (persistent GEMM, attention, row_norm); see
 // xcd_remap_dir in common.h. Set by the block composites, false for direct calls of the single-kernel entry points.
 void walk_reverse(bool on);
@@ -61,6 +62,14 @@ struct RowNormArgs {
   float* out8_scale = nullptr;  // scale amax / 448 [rows] (the fp8 A operand of the next GEMM; same rule as quantize_rows_fp8)
 };
 int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
+
+// ---- skinny.hip: small-M GEMM (bf16, K in {768, 1024}), bit-identical to the tile kernels; optional AdaLN-modulate prologue
+bool skinny_gemm_fits(int M, int N, int K, bool modulate);
+int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
+                const RowNormArgs* pro, hipStream_t st);
+// out = act(modulate(pro) W^T + bias): one launch where skinny.hip applies, else row_norm into pro.out followed by the GEMM
+int gemm_modulate_act(const RowNormArgs& pro, const void* W, const float* bias, void* out, int M, int N, int K, int act,
+                      int dtype, hipStream_t st);
 
 int rope_table(const float* pos, const long long* ids, float* table, int nb, int pad, int n_tok, int n_pos,
                int hd, const float* inv_freq, hipStream_t st);

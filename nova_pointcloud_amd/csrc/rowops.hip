@@ -16,6 +16,7 @@
 //                    (diffusion_mlp.py:65-75,89-99; guidance_scaler.py:86-87; scheduling_cfm.py:134-136)
 #include "common.h"
 #include "nova_internal.h"
+#include "rownorm.h"
 
 namespace nova {
 
@@ -36,40 +37,6 @@ template <> struct Vec4<bf16_t> {
   }
 };
 
-// One wave per row, 16-byte accesses (8 bf16 / 4 f32 per lane per chunk), the whole row (D <= 2048) held in
-// registers; the residual / modulation rows are requested together with the input row so that all of a row's
-// HBM traffic is in flight before the two wave reductions.
-template <typename T> struct Chunk;  // 16 bytes of a row as float values
-template <> struct Chunk<float> {
-  static constexpr int N = 4;
-  f4v v[1];
-  static __device__ __forceinline__ Chunk load(const float* p) { Chunk c; c.v[0] = *reinterpret_cast<const f4v*>(p); return c; }
-  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f4v*>(p) = v[0]; }
-  __device__ __forceinline__ Chunk rounded() const { return *this; }
-};
-template <> struct Chunk<bf16_t> {
-  static constexpr int N = 8;
-  f4v v[2];
-  static __device__ __forceinline__ Chunk load(const bf16_t* p) {
-    const u4v u = *reinterpret_cast<const u4v*>(p);
-    Chunk c;
-    c.v[0] = f4v{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
-    c.v[1] = f4v{__uint_as_float(u[2] << 16), __uint_as_float(u[2] & 0xffff0000u), __uint_as_float(u[3] << 16), __uint_as_float(u[3] & 0xffff0000u)};
-    return c;
-  }
-  __device__ __forceinline__ void store(bf16_t* p) const {
-    u4v u = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]), pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
-    *reinterpret_cast<u4v*>(p) = u;
-  }
-  __device__ __forceinline__ Chunk rounded() const {  // the values as they read back after store(): rounded to bf16
-    const u4v u = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]), pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
-    Chunk c;
-    c.v[0] = f4v{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
-    c.v[1] = f4v{__uint_as_float(u[2] << 16), __uint_as_float(u[2] & 0xffff0000u), __uint_as_float(u[3] << 16), __uint_as_float(u[3] & 0xffff0000u)};
-    return c;
-  }
-};
-
 template <typename T, int NIT, bool HAS_RES, bool HAS_MOD>
 __global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
   using C = Chunk<T>;
@@ -78,41 +45,8 @@ __global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
   // XCD x walks one contiguous eighth of the rows, front to back or back to front (xcd_remap_dir, common.h)
   const long row = (long)xcd_remap_dir(blockIdx.x, gridDim.x, a.rev != 0) * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
-  const long src = a.gather ? (long)a.gather[row] : row;
-  const T* in = static_cast<const T*>(a.in) + src * a.D;
-  const T* mod = HAS_MOD ? static_cast<const T*>(a.mod) + row * a.mod_ld : nullptr;
-  const T* res = HAS_RES ? static_cast<const T*>(a.res) + row * a.D : nullptr;
-  const bool has_ss = HAS_MOD && a.scale_off >= 0, has_gate = HAS_MOD && a.gate_off >= 0;
-  C x[NIT], r[HAS_RES ? NIT : 1], ms[HAS_MOD ? NIT : 1], mb[HAS_MOD ? NIT : 1], mg[HAS_MOD ? NIT : 1];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int d = (it * 64 + lane) * C::N;
-    if (d < a.D) {
-      x[it] = C::load(in + d);
-      if (HAS_RES) r[it] = C::load(res + d);
-      if (has_ss) { ms[it] = C::load(mod + a.scale_off + d); mb[it] = C::load(mod + a.shift_off + d); }
-      if (has_gate) mg[it] = C::load(mod + a.gate_off + d);
-    }
-  }
-  float sum = 0.f;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it)
-    if ((it * 64 + lane) * C::N < a.D)
-#pragma unroll
-      for (int k = 0; k < NV; ++k) sum += (x[it].v[k][0] + x[it].v[k][1]) + (x[it].v[k][2] + x[it].v[k][3]);
-  const float mean = wave_sum(sum) / (float)a.D;
-  float sq = 0.f;
-#pragma unroll
-  for (int it = 0; it < NIT; ++it)
-    if ((it * 64 + lane) * C::N < a.D)
-#pragma unroll
-      for (int k = 0; k < NV; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float c = x[it].v[k][j] - mean;
-          sq += c * c;
-        }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)a.D + a.eps);
+  C x[NIT];  // the finished row (rownorm.h: all of a row's HBM traffic is in flight before the two wave reductions)
+  row_norm_compute<T, NIT, HAS_RES, HAS_MOD>(a, row, lane, x);
   T* out = static_cast<T*>(a.out) + row * a.D;
   const bool q8 = sizeof(T) == 2 && a.out8 != nullptr;  // also emit the row as e4m3 + scale (what the next fp8 GEMM reads)
   float amax = 0.f;
@@ -120,31 +54,19 @@ __global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
   for (int it = 0; it < NIT; ++it) {
     const int d = (it * 64 + lane) * C::N;
     if (d < a.D) {
-      C y;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) {
-        f4v v = (x[it].v[k] - mean) * rstd;
-        if (a.gamma) v = v * *reinterpret_cast<const f4v*>(a.gamma + d + 4 * k) + *reinterpret_cast<const f4v*>(a.beta + d + 4 * k);
-        if (has_ss) v = v * (1.0f + ms[it].v[k]) + mb[it].v[k];
-        if (has_gate) v = v * mg[it].v[k];
-        if (HAS_RES) v = v + r[it].v[k];
-        y.v[k] = v;
-      }
-      y.store(out + d);
+      x[it].store(out + d);
       if (q8) {  // quantise what was STORED (the bf16-rounded row), so the fp8 copy equals quantize_rows_fp8(out)
-        y = y.rounded();
-        x[it] = y;
+        x[it] = x[it].rounded();
 #pragma unroll
         for (int k = 0; k < NV; ++k)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(y.v[k][j]));
+          for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(x[it].v[k][j]));
       }
     }
   }
   if constexpr (sizeof(T) == 2) {
     if (q8) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      amax = wave_max(amax);
       const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
       const float inv = 1.0f / sc;
       if (lane == 0) a.out8_scale[row] = sc;
@@ -397,8 +319,7 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
         for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(v[it].v[k][j]));
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  amax = wave_max(amax);
   const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
   const float inv = 1.0f / sc;
   if (lane == 0) scale[row] = sc;

@@ -1,0 +1,158 @@
+// NOVA hot path: small-M projection GEMM for the diffusion MLP's per-step launches
+//   out[M,N] = act(pro(A)[M,K] · W[N,K]^T + bias[N]),   M = (guidance passes x batch) x tokens predicted in this AR step
+// (reference diffnext/models/diffusion_mlp.py:31-36,41-47: DiffusionBlock = AdaLN modulate -> fc1 -> SiLU -> fc2 -> gated
+// norm; 25 denoising steps x 6 blocks per AR step, transformer_3d.py:102-113). At batch 8 these GEMMs have a few hundred
+// rows: the 128x128-tile kernel then runs 12-48 workgroups through a 12-16 deep chain of barrier-separated K-tiles
+// (14.5 us per launch, 25 TFLOP/s) and the AdaLN modulate ahead of fc1 is a launch of its own (6 us for 256 rows).
+//
+// Structure: a workgroup owns 16 rows x 64 columns and the WHOLE K extent (K in {768, 1024}: d48w768 / d48w1024).
+//   * the weight fragments of a wave's 16 columns go global -> registers directly, all K/32 of them requested before
+//     anything else (each element is used by exactly one wave: staging it through LDS would buy nothing);
+//   * the 16 activation rows are written to LDS once, either copied or - PRO - produced by the AdaLN modulate
+//     LN(x)(1 + scale) + shift itself (rownorm.h: the arithmetic of row_norm_kernel, one wave per row), so the
+//     modulate launch disappears; every column tile recomputes its 16 rows, which is cheap next to a launch;
+//   * one barrier, then K/32 MFMAs per wave in K order on one accumulator that starts at the bias.
+// Same MFMA (v_mfma_f32_16x16x32_bf16, weight fragment as A operand), same K order, same lane <-> k-slice placement,
+// same epilogue functions as gemm_kernel / gemm256: results are BIT-IDENTICAL to the large-tile kernels, so the
+// choice of kernel by M never shows in the output (batch and lane splits stay exact; tests compare bit for bit).
+#include "common.h"
+#include "nova_internal.h"
+#include "rownorm.h"
+
+namespace nova {
+
+constexpr int SK_R = 16, SK_C = 64;
+
+template <int K, int EPI, bool PRO>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                          bf16_t* __restrict__ C, int M, int N, const float* __restrict__ bias,
+                                                          RowNormArgs pro) {
+  constexpr int NS = K / 32;            // MFMA steps
+  constexpr int LROW = K * 2 + 16;      // LDS row pitch: +16 B so the 16 rows of a fragment read start in different banks
+  constexpr int NIT = (K / 8 + 63) / 64;
+  __shared__ __attribute__((aligned(16))) char smem[SK_R * LROW];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ntn = N / SK_C;
+  const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
+  const int m0 = tm * SK_R, n0 = tn * SK_C + wid * 16;
+
+  // ---- weights: lane (fr, fg) holds W[n0 + fr][32 s + 8 fg .. + 8] for every step s
+  bf8v wf[NS];
+  {
+    const bf16_t* wp = W + (size_t)(n0 + fr) * K + 8 * fg;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) wf[s] = *reinterpret_cast<const bf8v*>(wp + 32 * s);
+  }
+  f4v acc = {0.f, 0.f, 0.f, 0.f};
+  if (bias) acc = *reinterpret_cast<const f4v*>(bias + n0 + 4 * fg);
+
+  // ---- activation rows -> LDS; wave w owns rows 4w .. 4w+3 (rows past M repeat row M-1 and are never stored); the
+  // loads of all four rows are requested before the first row's reductions
+  if (PRO) {
+    RowRegs<bf16_t, NIT, false, true> g[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) row_norm_load<bf16_t, NIT, false, true>(pro, min(m0 + wid * 4 + i, M - 1), lane, g[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Chunk<bf16_t> y[NIT];
+      row_norm_finish<bf16_t, NIT, false, true>(pro, lane, g[i], y);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int d = (it * 64 + lane) * 8;
+        if (d < K) {
+          const u4v u = {pack_bf2(y[it].v[0][0], y[it].v[0][1]), pack_bf2(y[it].v[0][2], y[it].v[0][3]),
+                         pack_bf2(y[it].v[1][0], y[it].v[1][1]), pack_bf2(y[it].v[1][2], y[it].v[1][3])};
+          *reinterpret_cast<u4v*>(smem + (wid * 4 + i) * LROW + d * 2) = u;
+        }
+      }
+    }
+  } else {
+    u4v raw[4][NIT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int d = (it * 64 + lane) * 8;
+        if (d < K) raw[i][it] = *reinterpret_cast<const u4v*>(A + (size_t)min(m0 + wid * 4 + i, M - 1) * K + d);
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int d = (it * 64 + lane) * 8;
+        if (d < K) *reinterpret_cast<u4v*>(smem + (wid * 4 + i) * LROW + d * 2) = raw[i][it];
+      }
+  }
+  __syncthreads();
+
+  // ---- K/32 MFMAs, K order
+  const char* ap = smem + fr * LROW + 16 * fg;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const bf8v af = *reinterpret_cast<const bf8v*>(ap + 64 * s);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af, acc, 0, 0, 0);
+  }
+
+  // ---- epilogue: lane holds out[m0 + fr][n0 + 4 fg .. + 4]
+  const int m = m0 + fr;
+  if (m < M) {
+    if (EPI == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = gelu_erf_fast(acc[j]);
+    } else if (EPI == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = silu(acc[j]);
+    }
+    const u2v o = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+    *reinterpret_cast<u2v*>(C + (size_t)m * N + n0 + 4 * fg) = o;
+  }
+}
+
+template <int K, bool PRO>
+static void launch_skinny(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, int act,
+                          const RowNormArgs& pro, hipStream_t st) {
+  const dim3 grid((unsigned)(((M + SK_R - 1) / SK_R) * (N / SK_C))), block(256);
+  switch (act) {
+    case 0: hipLaunchKernelGGL((skinny_gemm_kernel<K, 0, PRO>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+    case 1: hipLaunchKernelGGL((skinny_gemm_kernel<K, 1, PRO>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+    default: hipLaunchKernelGGL((skinny_gemm_kernel<K, 2, PRO>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+  }
+}
+
+// Shapes this kernel is built for and worth using on: every row tile re-reads the whole weight matrix and every column
+// tile its 16 activation rows (x 3 with the modulate prologue), all from L2; past ~64 MB of such traffic per launch the
+// 128-tile kernel is faster (tools/skinny_bench.py).
+bool skinny_gemm_fits(int M, int N, int K, bool modulate) {
+  if (M <= 0 || (K != 768 && K != 1024) || N % SK_C != 0) return false;
+  const double row_tiles = (M + SK_R - 1) / SK_R, col_tiles = N / SK_C;
+  const double bytes = row_tiles * (double)N * K * 2.0 + col_tiles * row_tiles * SK_R * (double)K * 2.0 * (modulate ? 3.0 : 1.0);
+  return bytes <= 64.0e6;
+}
+
+// `pro` null: plain GEMM on A. Otherwise pro->in / mod / scale_off / shift_off / eps describe the AdaLN modulate whose
+// result is the A operand (pro->out, gamma, res, gate and gather are not used: the m1 form of diffusion_mlp.py:41-43).
+int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
+                const RowNormArgs* pro, hipStream_t st) {
+  if (M <= 0) return 0;
+  if ((K != 768 && K != 1024) || N % SK_C != 0) return set_error(NOVA_ERR_SHAPE, "skinny_gemm: need K in {768, 1024} and N %% 64 == 0 (got N=%d K=%d)", N, K);
+  if (act < 0 || act > 2) return set_error(NOVA_ERR_ARG, "skinny_gemm: unknown activation %d", act);
+  if (pro && (pro->D != K || pro->rows < M || !pro->in || !pro->mod || pro->scale_off < 0 || pro->shift_off < 0 || pro->gate_off >= 0 ||
+              pro->gamma || pro->res || pro->gather || pro->mod_ld % 8 || pro->scale_off % 8 || pro->shift_off % 8))
+    return set_error(NOVA_ERR_ARG, "skinny_gemm: the prologue is the scale/shift modulate of %d-wide rows only", K);
+  ProfScope prof(PROF_GEMM_SMALL, 2.0 * M * N * K, st);
+  const bf16_t* a = static_cast<const bf16_t*>(A);
+  const bf16_t* w = static_cast<const bf16_t*>(W);
+  bf16_t* c = static_cast<bf16_t*>(out);
+  const RowNormArgs none{};
+  if (K == 768) {
+    if (pro) launch_skinny<768, true>(a, w, c, M, N, bias, act, *pro, st);
+    else launch_skinny<768, false>(a, w, c, M, N, bias, act, none, st);
+  } else {
+    if (pro) launch_skinny<1024, true>(a, w, c, M, N, bias, act, *pro, st);
+    else launch_skinny<1024, false>(a, w, c, M, N, bias, act, none, st);
+  }
+  return check_launch("skinny_gemm");
+}
+
+}  // namespace nova

@@ -178,7 +178,7 @@ class NovaEngine(object):
         self.sig = None
         self.fp8 = False
         self.fp8_delayed = True
-        self.ws_key, self.ws = None, {}
+        self.ws = {}  # lane -> (shape key, buffers)
 
     # ------------------------------------------------------------------ packing / workspaces
     @classmethod
@@ -201,6 +201,7 @@ class NovaEngine(object):
         self.D = ie.embed_dim
         self.heads = ie.blocks[0].attn.num_heads
         self.hidden = ie.blocks[0].mlp.fc1.out_features
+        self.P = ie.patch_embed.patch_size ** 2 * ie.image_dim  # values per point token (xyz for point sets)
         self.video = pack_vit_blocks(list(ve.blocks), dtype)
         half = ie.encoder_depth
         self.enc1 = pack_vit_blocks(list(ie.blocks[:half]), dtype)
@@ -234,6 +235,10 @@ class NovaEngine(object):
         if hasattr(vpe, "time_proj"):  # abs-PE checkpoints: VideoPosEmbed's frame-index MLP (embeddings.py:94-111)
             self.vtime = (pk.w(vpe.time_proj[0].weight, dtype), pk.f(vpe.time_proj[0].bias), pk.w(vpe.time_proj[2].weight, dtype),
                           pk.f(vpe.time_proj[2].bias), pk.f(vpe.norm.weight), pk.f(vpe.norm.bias))
+        self.motion = None
+        if m.motion_embed is not None:  # MotionEmbed's (flow, fps) MLPs (embeddings.py:119-137)
+            self.motion = [(pk.w(pr[0].weight, dtype), pk.f(pr[0].bias), pk.w(pr[2].weight, dtype), pk.f(pr[2].bias))
+                           for pr in (m.motion_embed.flow_proj, m.motion_embed.fps_proj)]
         self.sig = sig
 
     # AdaLN projections of all diffusion steps in one GEMM (nova_decoder_denoise mod_steps = steps) when the steps-times
@@ -241,26 +246,22 @@ class NovaEngine(object):
     MOD_HOIST_BYTES = 12 << 30
 
     def _workspace(self, S, B, N, L, nmax, lane=0, steps=1):
+        """Scratch buffers of one lane, reallocated only when the shapes (or dtype / fp8 mode) change."""
         key = (S, B, N, L, nmax, self.dtype, self.dev, self.fp8, steps)
-        if lane:  # additional lanes keep their own buffers
-            cache = self.__dict__.setdefault("_lane_ws", {})
-            if cache.get(lane, (None, None))[0] != key:
-                saved = (self.ws_key, self.ws)
-                self.ws_key = None
-                cache[lane] = (key, dict(self._workspace(S, B, N, L, nmax, 0, steps)))
-                self.ws_key, self.ws = saved
-            return cache[lane][1]
-        if key != self.ws_key:
+        if self.ws.get(lane, (None, None))[0] != key:
             D, dt, dev = self.D, self.dtype, self.dev
             e = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
             rows = S * L
-            self.ws = dict(x8=torch.empty(rows, D, dtype=torch.uint8, device=dev), xs=torch.empty(rows, dtype=_F32, device=dev),
-                           h8=torch.empty(rows, self.hidden, dtype=torch.uint8, device=dev), hs=torch.empty(rows, dtype=_F32, device=dev)) if self.fp8 else {}
-            self.ws.update(x1=e(rows, D), x2=e(rows, D), qkv=e(rows, 3 * D), a=e(rows, D), b=e(rows, D),
-                           h=e(rows, self.hidden), z0=e(B * N, D), da=e(steps * S * nmax, D), du=e(S * nmax, D), dh=e(S * nmax, D),
-                           df=e(S * nmax, D), dg=e(S * nmax, D), dmod=e(steps * S * nmax, (3 * self.dec.depth + 2) * D))
-            self.ws_key = key
-        return self.ws
+            ws = dict(x8=torch.empty(rows, D, dtype=torch.uint8, device=dev), xs=torch.empty(rows, dtype=_F32, device=dev),
+                      h8=torch.empty(rows, self.hidden, dtype=torch.uint8, device=dev), hs=torch.empty(rows, dtype=_F32, device=dev)) if self.fp8 else {}
+            ws.update(x1=e(rows, D), x2=e(rows, D), qkv=e(rows, 3 * D), a=e(rows, D), b=e(rows, D),
+                      h=e(rows, self.hidden), z0=e(B * N, D), da=e(steps * S * nmax, D), du=e(S * nmax, D), dh=e(S * nmax, D),
+                      df=e(S * nmax, D), dg=e(S * nmax, D), dmod=e(steps * S * nmax, (3 * self.dec.depth + 2) * D),
+                      # operands of nova_decoder_denoise at addresses that do not change from call to call (its launch
+                      # sequence is replayed as a hipGraph keyed by its arguments): condition rows and the rows being denoised
+                      dz=e(S * nmax, D), dx=torch.empty(B * nmax * self.P, dtype=_F32, device=dev), temb={})
+            self.ws[lane] = (key, ws)
+        return self.ws[lane][1]
 
     # ------------------------------------------------------------------ building blocks
     def _blocks(self, pack, x, S, L, rope, rope_batch, ws):
@@ -289,9 +290,9 @@ class NovaEngine(object):
                  hip.ptr(rope), rope_batch, ws["qkv"].data_ptr(), ws["a"].data_ptr(), ws["b"].data_ptr(),
                  ws["h"].data_ptr(), self.code, hip.stream_ptr())
 
-    def _gemm(self, a, w_ptr, b_ptr, N, act=hip.ACT_NONE):
+    def _gemm(self, a, w_ptr, b_ptr, N, act=hip.ACT_NONE, out=None):
         M, K = a.shape
-        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device) if out is None else out
         hip.call("nova_gemm_bias_act", a.data_ptr(), w_ptr, b_ptr, out.data_ptr(), M, N, K, act, self.code, hip.stream_ptr())
         return out
 
@@ -456,7 +457,9 @@ class NovaEngine(object):
         runs = []
         for k, (lo, hi) in enumerate(bounds):
             pick = lambda t: torch.cat([t[q * B + lo:q * B + hi] for q in range(passes)]).contiguous()
-            stream = main if lanes == 1 else self._lane_stream(k)
+            # a single lane stays on the caller's stream unless that is the legacy default stream, which cannot be
+            # captured (nova_decoder_denoise replays its launch sequence as a hipGraph)
+            stream = main if (lanes == 1 and main != torch.cuda.default_stream(dev)) else self._lane_stream(k)
             ctx = dict(k=k, lo=lo, hi=hi, prompt=pick(prompt), motion=None if motion is None else pick(motion),
                        order=order[lo:hi].contiguous(), stream=stream, inbox=None, frames=[],
                        first=None if first is None else first[lo:hi])
@@ -464,7 +467,7 @@ class NovaEngine(object):
                                          num_preds=num_preds, cfg_on=cfg_on)))
 
         def advance(ctx, gen):
-            if lanes > 1:
+            if ctx["stream"] is not main:
                 ctx["stream"].wait_stream(main)
                 with torch.cuda.stream(ctx["stream"]):
                     return next(gen, None)
@@ -482,7 +485,7 @@ class NovaEngine(object):
                 for ctx, gen in runs:
                     lo, hi = ctx["lo"], ctx["hi"]
                     ctx["inbox"] = (nz[lo:hi], None if extra is None else [None if e is None else e[lo:hi] for e in extra])
-                    if lanes > 1:  # tensors made on the main stream, consumed on the lane's stream
+                    if ctx["stream"] is not main:  # tensors made on the main stream, consumed on the lane's stream
                         nz.record_stream(ctx["stream"])
                         [e.record_stream(ctx["stream"]) for e in (extra or []) if e is not None]
                     advance(ctx, gen)
@@ -490,7 +493,7 @@ class NovaEngine(object):
         canvas = torch.empty(nf, B, N, P, dtype=_F32, device=dev)
         mask = torch.empty(B, N, dtype=_F32, device=dev)
         for ctx, gen in runs:
-            if lanes > 1:
+            if ctx["stream"] is not main:
                 main.wait_stream(ctx["stream"])
             for f in range(nf):
                 canvas[f, ctx["lo"]:ctx["hi"]] = ctx["frames"][f]
@@ -510,13 +513,8 @@ class NovaEngine(object):
     def _motion_tokens(self, values):
         """MotionEmbed.forward (embeddings.py:119-137): [S, 2] (flow, fps) -> two condition tokens per row [S, 2, D]."""
         me = self.model.motion_embed
-        cache = self.misc.__dict__.setdefault("motion", None)
-        if cache is None:
-            pk = self.misc
-            cache = self.misc.motion = [(pk.w(pr[0].weight, self.dtype), pk.f(pr[0].bias), pk.w(pr[2].weight, self.dtype), pk.f(pr[2].bias))
-                                        for pr in (me.flow_proj, me.fps_proj)]
         toks = []
-        for col, (w1, b1, w2, b2) in enumerate(cache):
+        for col, (w1, b1, w2, b2) in enumerate(self.motion):
             ang = values[:, col].reshape(-1, 1).float() * me.freq_m.reshape(1, -1)
             feats = torch.cat([ang.sin(), ang.cos()], dim=-1).to(device=self.dev, dtype=self.dtype).contiguous()
             toks.append(self._gemm(self._gemm(feats, w1, b1, self.D, hip.ACT_SILU), w2, b2, self.D))
@@ -579,7 +577,10 @@ class NovaEngine(object):
         c_txt = self._norm_rows(self._gemm(pr, self.text[0], self.text[1], D), self.text[2:])
         if ctx["motion"] is not None:
             c_txt = torch.cat([c_txt.view(S, Lt, D), self._motion_tokens(ctx["motion"])], dim=1).reshape(S * Lp, D).contiguous()
-        temb = self.timestep_table(timesteps)
+        temb = ws["temb"].get(steps)
+        if temb is None:
+            temb = ws["temb"][steps] = torch.empty(steps, D, dtype=dtype, device=dev)
+        temb.copy_(self.timestep_table(timesteps))
 
         # ---- positions / absolute position tables
         rope_i = pos_img = inv_freq = inv_freq_v = img_pe = vpos = None
@@ -687,11 +688,11 @@ class NovaEngine(object):
                 # final LN only on the rows predicted now, then the condition projection (time term added per step)
                 zc = self._norm_rows(y, self.inorm)
                 w1, b1, w2, b2 = self.dec.time[1]
-                zc = self._gemm(self._gemm(zc, w1, b1, D, hip.ACT_SILU), w2, b2, D)
+                zc = self._gemm(self._gemm(zc, w1, b1, D, hip.ACT_SILU), w2, b2, D, out=ws["dz"][: S * n])
                 # this step's noise rows (drawn by the caller for the whole batch)
                 nz, extra = ctx["inbox"]
                 idx = pred_ids[..., None].expand(-1, -1, P)
-                x_n = nz.gather(1, idx).contiguous()
+                x_n = torch.gather(nz, 1, idx, out=ws["dx"][: B * n * P].view(B, n, P))
                 step_noise = echo = ws_v = None
                 if ancestral:
                     step_noise = torch.stack([torch.zeros(B, n, P, dtype=_F32, device=dev) if e is None else e.gather(1, idx)

@@ -89,11 +89,15 @@ SIGNATURES = {
     "nova_pointset_nn_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_int, c_void_p],
     "nova_pointset_pairwise_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_void_p],
     "nova_modulate_rows": [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p],
+    "nova_adaln_fc1": [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_long]
+    + [c_int] * 4 + [c_void_p],
     "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]
     + [c_int] * 6 + [c_void_p] * 7 + [c_int, c_int, c_void_p],
 }
 SIGNATURES["nova_prof_enable"] = [c_int]
 SIGNATURES["nova_debug_force_gemm_tile"] = [c_int]
+SIGNATURES["nova_debug_set_graphs"] = [c_int]
+SIGNATURES["nova_debug_graph_stats"] = [ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
 SIGNATURES["nova_prof_collect"] = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_longlong), c_int]
 PROF_SLOTS = ["gemm_bias", "gemm_bias_gelu", "gemm_bias_silu", "qkv_gemm_rope", "attention", "row_norm", "gemm_small_tile"]
@@ -246,6 +250,30 @@ def row_norm(x, out=None, gamma=None, beta=None, mod=None, scale_off=-1, shift_o
          scale_off, shift_off, gate_off, ptr(res), ptr(gather, torch.int32), rows, D, float(eps),
          dtype_code(x.dtype), stream_ptr())
     return out
+
+
+def adaln_fc1(x, mod, scale_off, shift_off, w, bias=None, act=ACT_SILU, eps=1e-6, out=None):
+    """act((LN(x) * (1 + mod[:, scale_off:+D]) + mod[:, shift_off:+D]) @ w^T + bias): DiffusionBlock's modulate -> fc1 -> SiLU
+    (diffusion_mlp.py:41-47); one launch at small row counts for bf16 rows of width 768 / 1024, else LN launch + GEMM."""
+    rows, D = x.shape
+    N = w.shape[0]
+    out = x.new_empty(rows, N) if out is None else out
+    h = x.new_empty(rows, D)
+    call("nova_adaln_fc1", ptr(x), ptr(mod), mod.shape[-1], scale_off, shift_off, float(eps), ptr(w), ptr(bias, torch.float32),
+         ptr(h), ptr(out), rows, N, D, act, dtype_code(x.dtype), stream_ptr())
+    return out
+
+
+def set_graphs(on=True):
+    """hipGraph replay of nova_decoder_denoise's launch sequence (default on; NOVA_GRAPHS=0 in the environment disables)."""
+    call("nova_debug_set_graphs", 1 if on else 0)
+
+
+def graph_stats():
+    """(graphs captured, graphs replayed) by the calling thread."""
+    c, r = c_long(0), c_long(0)
+    call("nova_debug_graph_stats", ctypes.byref(c), ctypes.byref(r))
+    return c.value, r.value
 
 
 def prof_enable(on=True):

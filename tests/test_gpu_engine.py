@@ -446,6 +446,38 @@ def test_fp8_gemm_mode_small_model(hip):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_decoder_graph_replay_equals_direct_launches(gold, hip, dtype):
+    """nova_decoder_denoise captures its launch sequence per argument set and replays it as a hipGraph: the first call
+    of a pipeline captures (one graph per AR step and lane), a second call with the same schedule replays every one of
+    them, and both equal the direct-launch path bit for bit (guidance decay changes the sampler plan between AR steps,
+    so a stale graph would show)."""
+    order, noises = gold.t["out/order"][..., 0], gold.t["in/noises"]
+    kw = dict(prompt_embeds=gold.prompt_embeds, num_inference_steps=gold.meta["K"], num_diffusion_steps=gold.meta["S"],
+              guidance_scale=gold.meta["guidance"], output_type="latent", disable_progress_bar=True, pred_order=order,
+              noise_fn=lambda i: noises[i])
+    hip.set_graphs(True)
+    try:
+        c0, r0 = hip.graph_stats()
+        pipe, first = run_pipe(gold, dtype, pred_order=order, noise_fn=lambda i: noises[i])
+        c1, r1 = hip.graph_stats()
+        second = pipe(**kw).frames
+        c2, r2 = hip.graph_stats()
+        third = pipe(**dict(kw, guidance_scale=gold.meta["guidance"] + 1.0)).frames  # another plan: new graphs, not the old ones
+        c3, r3 = hip.graph_stats()
+        assert c1 > c0 and r1 == r0, "first call captures"
+        assert c2 == c1 and r2 - r1 == c1 - c0, "second call replays every graph of the first"
+        assert c3 > c2
+        hip.set_graphs(False)
+        direct = pipe(**kw).frames
+        direct3 = pipe(**dict(kw, guidance_scale=gold.meta["guidance"] + 1.0)).frames
+        assert hip.graph_stats()[1] == r3
+    finally:
+        hip.set_graphs(True)
+    assert torch.equal(first, direct) and torch.equal(second, direct)
+    assert torch.equal(third, direct3) and not torch.equal(third, direct)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_adaln_projection_hoisted_over_steps_equals_per_step(gold, hip, dtype):
     """nova_decoder_denoise mod_steps = steps (one AdaLN GEMM for all diffusion steps) against mod_steps = 1: identical
     points, with guidance truncation switching the pass count mid-loop as well."""

@@ -295,6 +295,59 @@ def test_gemm_256_tile_bitwise_equals_128_tile(hip, force_tile, form, dtype, M, 
     assert relerr(out, full) < tol(dtype)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1, 768, 768, 0), (16, 768, 768, 2), (200, 768, 768, 2), (257, 3072, 768, 1), (999, 1024, 1024, 2),
+                                        (130, 4096, 1024, 1), (64, 64, 1024, 0)])
+def test_small_m_gemm_bitwise_equals_tile_kernels(hip, force_tile, M, N, K, act):
+    """skinny.hip (whole-K workgroups, weights global -> registers) against the 128-tile kernel, bit for bit: the kernel
+    picked by the row count must never show in the result (batch / lane splits of the engine rely on it)."""
+    dtype = torch.bfloat16
+    a, w = rnd(M, K, dtype=dtype, seed=51), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=52)
+    bias = rnd(N, seed=53)
+    force_tile(16)
+    out = hip.gemm_bias_act(a, w, bias, act)
+    out_nb = hip.gemm_bias_act(a, w, None, act)
+    if N % 128 == 0:
+        force_tile(128)
+        assert torch.equal(out, hip.gemm_bias_act(a, w, bias, act))
+        assert torch.equal(out_nb, hip.gemm_bias_act(a, w, None, act))
+    full = a.float() @ w.float().T + bias
+    full = [lambda x: x, torch.nn.functional.gelu, torch.nn.functional.silu][act](full)
+    assert relerr(out, full) < tol(dtype)
+    force_tile(0)  # the automatic choice (small-M kernel at these sizes where it pays) gives the same bits again
+    assert torch.equal(out, hip.gemm_bias_act(a, w, bias, act))
+
+
+def test_small_m_gemm_rejects_other_shapes(hip, force_tile):
+    force_tile(16)
+    a, w = rnd(32, 512, dtype=torch.bfloat16), rnd(128, 512, dtype=torch.bfloat16)
+    with pytest.raises(hip.NovaHipError):
+        hip.gemm_bias_act(a, w, None, 0)
+
+
+@pytest.mark.parametrize("rows,D,N", [(1, 768, 768), (37, 768, 768), (256, 768, 768), (300, 1024, 1024), (77, 1024, 2048)])
+def test_adaln_fc1_fused_equals_two_launches(hip, force_tile, rows, D, N):
+    """modulate -> fc1 -> SiLU (diffusion_mlp.py:41-47) as ONE launch (LN prologue inside the small-M GEMM) against
+    nova_row_norm followed by the GEMM: identical bits, and both close to fp32 math."""
+    dtype = torch.bfloat16
+    x = rnd(rows, D, dtype=dtype, seed=61)
+    mod = rnd(rows, 5 * D, dtype=dtype, scale=0.5, seed=62)
+    w, bias = rnd(N, D, dtype=dtype, scale=D ** -0.5, seed=63), rnd(N, seed=64)
+    force_tile(16)
+    fused = hip.adaln_fc1(x, mod, D, 3 * D, w, bias, act=2, eps=1e-6)
+    force_tile(128)
+    h = hip.row_norm(x, mod=mod, scale_off=D, shift_off=3 * D, eps=1e-6)
+    two = hip.gemm_bias_act(h, w, bias, 2)
+    assert torch.equal(fused, two)
+    assert torch.equal(fused, hip.adaln_fc1(x, mod, D, 3 * D, w, bias, act=2, eps=1e-6))  # forced 128: the two-launch form inside
+    ln = torch.nn.functional.layer_norm(x.float(), (D,), None, None, 1e-6)
+    hm = (ln * (1 + mod[:, D:2 * D].float()) + mod[:, 3 * D:4 * D].float()).to(dtype).float()
+    assert relerr(fused, torch.nn.functional.silu(hm @ w.float().T + bias)) < tol(dtype)
+    f32 = [t.float() for t in (x, mod, w)]  # f32 rows always take the two-launch form
+    force_tile(0)
+    o32 = hip.adaln_fc1(f32[0], f32[1], D, 3 * D, f32[2], bias, act=2, eps=1e-6)
+    assert relerr(o32, torch.nn.functional.silu((ln * (1 + f32[1][:, D:2 * D]) + f32[1][:, 3 * D:4 * D]) @ f32[2].T + bias)) < tol(torch.float32)
+
+
 @pytest.mark.parametrize("form", TILE256_FORMS)
 @pytest.mark.parametrize("S,L", [(4, 301), (16, 257), (3, 1400)])
 def test_gemm_256_tile_qkv_rope_bitwise(hip, force_tile, form, S, L):
