@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NOVA_HIP_VERSION 201 /* 0.2.1: nova_adaln_fc1 (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
+#define NOVA_HIP_VERSION 201 /* 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
 
 typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1 } nova_dtype;
 typedef enum { NOVA_ACT_NONE = 0, NOVA_ACT_GELU_ERF = 1, NOVA_ACT_SILU = 2 } nova_act;
@@ -128,6 +128,15 @@ int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, i
 int nova_row_norm(const void* in, void* out, const float* gamma, const float* beta, const void* mod, long mod_ld,
                   int scale_off, int shift_off, int gate_off, const void* res, const int* gather, long rows, int D,
                   float eps, int dtype, void* stream);
+
+/* Two chained row norms of the diffusion MLP in one pass over bf16 rows: x_new = (LN(g) gamma + beta) * mod[:, gate_off:+D]
+ * + x (eps_first; DiffusionBlock's `norm2(proj(h)).mul(gate).add_(x)`, diffusion_mlp.py:52-53), then h = LN(x_new)(1 +
+ * mod[:, scale_off:+D]) + mod[:, shift_off:+D] (eps_second, no affine; the next block's or the final layer's modulate,
+ * diffusion_mlp.py:41-43,96-97 / normalization.py:34-36). The second norm reads x_new as stored (rounded to bf16), so the
+ * result equals nova_row_norm twice, bit for bit. x_new_out may be NULL (x not needed afterwards: the last block). */
+int nova_row_norm_chain(const void* g, const void* x, const float* gamma, const float* beta, const void* mod, long mod_ld,
+                        int gate_off, int scale_off, int shift_off, float eps_first, float eps_second, void* x_new_out,
+                        void* h_out, long rows, int D, void* stream);
 
 /* out = act(h W^T + bias) with h = LN(x)(1 + mod[:, scale_off:+D]) + mod[:, shift_off:+D], LN without affine: the first
  * half of DiffusionBlock.forward, `self.proj(self.norm1(x, z)...)` up to the activation (diffusion_mlp.py:41-47 with

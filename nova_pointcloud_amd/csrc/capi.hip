@@ -195,6 +195,15 @@ int nova_row_norm(const void* in, void* out, const float* gamma, const float* be
   return row_norm(a, dtype, (hipStream_t)stream);
 }
 
+int nova_row_norm_chain(const void* g, const void* x, const float* gamma, const float* beta, const void* mod, long mod_ld,
+                        int gate_off, int scale_off, int shift_off, float eps_first, float eps_second, void* x_new_out,
+                        void* h_out, long rows, int D, void* stream) {
+  NOVA_REQUIRE(rows == 0 || (g && x && mod && h_out), NOVA_ERR_ARG, "row_norm_chain: null pointer");
+  RowNormArgs a2{g, nullptr, gamma, beta, mod, mod_ld, -1, -1, gate_off, x, nullptr, rows, D, eps_first};
+  RowNormArgs a1{nullptr, h_out, nullptr, nullptr, mod, mod_ld, scale_off, shift_off, -1, nullptr, nullptr, rows, D, eps_second};
+  return row_norm_chain(a2, a1, x_new_out, (hipStream_t)stream);
+}
+
 int nova_adaln_fc1(const void* x, const void* mod, long mod_ld, int scale_off, int shift_off, float eps, const void* w,
                    const float* bias, void* h, void* out, long rows, int N, int D, int act, int dtype, void* stream) {
   NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "adaln_fc1: bad dtype %d", dtype);
@@ -487,17 +496,24 @@ static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, con
       NOVA_TRY(gemm_modulate_act(m1, blk.fc1_w, blk.fc1_b, ws_f, (int)rows, D, D, NOVA_ACT_SILU, dtype, st));  // one launch at small M
       NOVA_TRY(gemm_bias_act(ws_f, blk.fc2_w, blk.fc2_b, ws_g, (int)rows, D, D, NOVA_ACT_NONE, dtype, st));
       RowNormArgs m2{ws_g, ws_u, blk.norm2_w, blk.norm2_b, ws_mod, mod_ld, -1, -1, b * 3 * D + 2 * D, ws_u, nullptr, rows, D, 1e-5f};
-      NOVA_TRY(row_norm(m2, dtype, st));
+      RowNormArgs mf{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, depth * 3 * D, depth * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
+      if (b == depth - 1 && dtype == NOVA_BF16) {
+        // last block: its gated norm + residual and the final layer's modulate in ONE row pass (x itself is not needed
+        // any more, so it is neither written nor read back); bit-identical to the two launches (rownorm.h)
+        NOVA_TRY(row_norm_chain(m2, mf, nullptr, st));
+      } else {
+        NOVA_TRY(row_norm(m2, dtype, st));
+        if (b == depth - 1) NOVA_TRY(row_norm(mf, dtype, st));
+      }
     }
-    RowNormArgs mf{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, depth * 3 * D, depth * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
-    NOVA_TRY(row_norm(mf, dtype, st));
+    const void* head_in = ws_h;
     const float* nz = (noise && sp.sigma != 0.f) ? noise + (size_t)i * nP : nullptr;
     if (do_renorm && cfg) {  // guidance_scaler.py:67-72: two small launches, norms over the whole sample
       float* extra = passes == 3 ? ws_v + 2 * nP : nullptr;
-      NOVA_TRY(head_cfg_step(ws_h, dec->head_w, dec->head_b, x, nullptr, ws_v, ws_v + nP, extra, B, n, P, D, sp, 1, dtype, st));
+      NOVA_TRY(head_cfg_step(head_in, dec->head_w, dec->head_b, x, nullptr, ws_v, ws_v + nP, extra, B, n, P, D, sp, 1, dtype, st));
       NOVA_TRY(renorm_euler(x, ws_v, ws_v + nP, extra, echo_energy, B, n, P, sp.c0, renorm, st));
     } else {
-      NOVA_TRY(head_cfg_step(ws_h, dec->head_w, dec->head_b, x, nz, nullptr, nullptr, nullptr, B, n, P, D, sp, 0, dtype, st));
+      NOVA_TRY(head_cfg_step(head_in, dec->head_w, dec->head_b, x, nz, nullptr, nullptr, nullptr, B, n, P, D, sp, 0, dtype, st));
       // guidance switched off for this step (guidance_trunc): no renorm, but the echo rows still take the Euler step
       if (do_renorm && echo_energy) NOVA_TRY(scale_vector(echo_energy, B, (1.0f + sp.c0) * (1.0f + sp.c0), st));
     }
@@ -507,12 +523,14 @@ static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, con
 
 
 // ---- hipGraph replay of the denoising loop.
-// One AR step issues steps x (3 x depth + 3) = 25 x 21 launches of 4-15 us kernels; at small batch with two stream lanes
-// the single host thread (about 9 us per launch) cannot keep both streams fed and the step becomes launch-bound
-// (tools/host_vs_gpu.py, tools/trace_gaps.py). The sequence is a pure function of the call's arguments, so it is captured
+// One AR step issues 25 x (15 to 27) launches of 4-15 us kernels from one host thread. The sequence is a pure function
+// of the call's arguments, so it is captured
 // once per distinct argument set - pointers, shapes, the per-step sampler plan and the decoder's weight pointers all
 // go into the key - and replayed with one hipGraphLaunch afterwards. The engine keeps every buffer of the call at a
 // stable address (workspace slots), so from the second generation on every AR step of a fixed schedule is a replay.
+// Measured (tools/host_vs_gpu.py): the host thread's time in a batch-8 generation call drops 907 -> 795 ms; wall time is
+// unchanged at batch 8 and 32 (the device, not the launch rate, bounds both), the first call of a schedule pays ~3 ms
+// per captured graph.
 // Calls that read per-call tensors the engine allocates afresh (ancestral noise, guidance-renorm scratch) and profiled
 // runs (HIP-event brackets around launches) stay on the direct path.
 struct DecoderGraphs {
@@ -563,6 +581,7 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
   NOVA_REQUIRE(dec && zc && temb && x && sched && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
                "decoder_denoise: null pointer");
   NOVA_REQUIRE(S == B || S == 2 * B || S == 3 * B, NOVA_ERR_SHAPE, "decoder_denoise: S must be B, 2B or 3B");
+  NOVA_REQUIRE(dec->depth >= 1 && dec->blocks, NOVA_ERR_ARG, "decoder_denoise: the decoder needs at least one block");
   const bool do_renorm = renorm < 1.0f;
   NOVA_REQUIRE(!do_renorm || (echo_energy && ws_v), NOVA_ERR_ARG, "decoder_denoise: renorm needs echo_energy and ws_v");
   if (n == 0 || B == 0) return 0;

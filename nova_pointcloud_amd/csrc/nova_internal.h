@@ -67,6 +67,7 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
 bool skinny_gemm_fits(int M, int N, int K, bool modulate);
 int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                 const RowNormArgs* pro, hipStream_t st);
+int row_norm_chain(const RowNormArgs& a2, const RowNormArgs& a1, void* x_new_out, hipStream_t st);  // rowops.hip, bf16: two chained norms, one pass
 // out = act(modulate(pro) W^T + bias): one launch where skinny.hip applies, else row_norm into pro.out followed by the GEMM
 int gemm_modulate_act(const RowNormArgs& pro, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                       int dtype, hipStream_t st);

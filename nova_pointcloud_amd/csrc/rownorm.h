@@ -56,7 +56,8 @@ struct RowRegs {
 };
 
 template <typename T, int NIT, bool HAS_RES, bool HAS_MOD>
-__device__ __forceinline__ void row_norm_load(const RowNormArgs& a, long row, int lane, RowRegs<T, NIT, HAS_RES, HAS_MOD>& g) {
+__device__ __forceinline__ void row_norm_load(const RowNormArgs& a, long row, int lane, RowRegs<T, NIT, HAS_RES, HAS_MOD>& g,
+                                              bool with_input = true) {
   using C = Chunk<T>;
   const long src = a.gather ? (long)a.gather[row] : row;
   const T* in = static_cast<const T*>(a.in) + src * a.D;
@@ -67,7 +68,7 @@ __device__ __forceinline__ void row_norm_load(const RowNormArgs& a, long row, in
   for (int it = 0; it < NIT; ++it) {
     const int d = (it * 64 + lane) * C::N;
     if (d < a.D) {
-      g.x[it] = C::load_raw(in + d);
+      if (with_input) g.x[it] = C::load_raw(in + d);
       if (HAS_RES) g.r[it] = C::load_raw(res + d);
       if (has_ss) { g.ms[it] = C::load_raw(mod + a.scale_off + d); g.mb[it] = C::load_raw(mod + a.shift_off + d); }
       if (has_gate) g.mg[it] = C::load_raw(mod + a.gate_off + d);
@@ -130,6 +131,38 @@ __device__ __forceinline__ void row_norm_compute(const RowNormArgs& a, long row,
   RowRegs<T, NIT, HAS_RES, HAS_MOD> g;
   row_norm_load<T, NIT, HAS_RES, HAS_MOD>(a, row, lane, g);
   row_norm_finish<T, NIT, HAS_RES, HAS_MOD>(a, lane, g, y);
+}
+
+// The block boundary of the diffusion MLP as ONE row pass (diffusion_mlp.py:52-53 then :41-43 of the next block, or the
+// final layer's modulate :96-97): x_new = LN(g) * gamma + beta) * gate + x, stored as bf16, then h = LN(x_new)(1 + scale)
+// + shift. a2 describes the first norm (in = g, res = x, gate_off, gamma / beta), a1 the second (scale_off / shift_off;
+// its `in` is not read). The second norm sees x_new exactly as it would read it back from memory (rounded to bf16), so
+// the chain equals row_norm(a2) followed by row_norm(a1) bit for bit. bf16 rows only.
+template <int NIT>
+struct RowChainRegs {
+  RowRegs<bf16_t, NIT, true, true> first;
+  RowRegs<bf16_t, NIT, false, true> second;
+};
+
+template <int NIT>
+__device__ __forceinline__ void row_chain_load(const RowNormArgs& a2, const RowNormArgs& a1, long row, int lane, RowChainRegs<NIT>& g) {
+  row_norm_load<bf16_t, NIT, true, true>(a2, row, lane, g.first);
+  row_norm_load<bf16_t, NIT, false, true>(a1, row, lane, g.second, false);
+}
+
+template <int NIT>
+__device__ __forceinline__ void row_chain_finish(const RowNormArgs& a2, const RowNormArgs& a1, int lane, RowChainRegs<NIT>& g,
+                                                 u4v (&x_new)[NIT], Chunk<bf16_t> (&y)[NIT]) {
+  Chunk<bf16_t> y2[NIT];
+  row_norm_finish<bf16_t, NIT, true, true>(a2, lane, g.first, y2);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it)
+    if ((it * 64 + lane) * 8 < a2.D) {
+      x_new[it] = u4v{pack_bf2(y2[it].v[0][0], y2[it].v[0][1]), pack_bf2(y2[it].v[0][2], y2[it].v[0][3]),
+                      pack_bf2(y2[it].v[1][0], y2[it].v[1][1]), pack_bf2(y2[it].v[1][2], y2[it].v[1][3])};
+      g.second.x[it] = x_new[it];
+    }
+  row_norm_finish<bf16_t, NIT, false, true>(a1, lane, g.second, y);
 }
 
 }  // namespace nova

@@ -126,6 +126,44 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
   return check_launch("row_norm");
 }
 
+template <int NIT>
+__global__ __launch_bounds__(256) void row_norm_chain_kernel(RowNormArgs a2, RowNormArgs a1, bf16_t* __restrict__ x_new_out) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a2.rows) return;
+  RowChainRegs<NIT> g;
+  row_chain_load<NIT>(a2, a1, row, lane, g);
+  u4v xn[NIT];
+  Chunk<bf16_t> y[NIT];
+  row_chain_finish<NIT>(a2, a1, lane, g, xn, y);
+  bf16_t* out = static_cast<bf16_t*>(a1.out) + row * a1.D;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int d = (it * 64 + lane) * 8;
+    if (d < a1.D) {
+      y[it].store(out + d);
+      if (x_new_out) *reinterpret_cast<u4v*>(x_new_out + row * a1.D + d) = xn[it];
+    }
+  }
+}
+
+// bf16 rows; a2 = gated affine norm with residual (its `out` is not used: x_new goes to x_new_out when that is given),
+// a1 = scale / shift modulate writing a1.out. Equals row_norm(a2) then row_norm(a1) bit for bit (rownorm.h).
+int row_norm_chain(const RowNormArgs& a2, const RowNormArgs& a1, void* x_new_out, hipStream_t st) {
+  if (a2.rows <= 0) return 0;
+  if (a2.D != a1.D || a2.rows != a1.rows || a2.D % 8 || a2.D > 2048) return set_error(NOVA_ERR_SHAPE, "row_norm_chain: bad shapes");
+  if (!a2.in || !a2.res || !a2.mod || a2.gate_off < 0 || a2.scale_off >= 0 || a2.gather || !a1.mod || a1.scale_off < 0 || a1.shift_off < 0 ||
+      a1.gate_off >= 0 || a1.gamma || a1.res || a1.gather || !a1.out || (a2.gamma == nullptr) != (a2.beta == nullptr))
+    return set_error(NOVA_ERR_ARG, "row_norm_chain: first norm = gate + residual, second = scale / shift modulate");
+  if (a2.mod_ld % 8 || a2.gate_off % 8 || a1.mod_ld % 8 || a1.scale_off % 8 || a1.shift_off % 8)
+    return set_error(NOVA_ERR_SHAPE, "row_norm_chain: modulation offsets must be multiples of 8");
+  const dim3 grid((unsigned)((a2.rows + 3) / 4));
+  ProfScope prof(PROF_ROWNORM, 2.0 * a2.rows * a2.D * 6.0, st);
+  if ((a2.D / 8 + 63) / 64 <= 2) hipLaunchKernelGGL(row_norm_chain_kernel<2>, grid, dim3(256), 0, st, a2, a1, static_cast<bf16_t*>(x_new_out));
+  else hipLaunchKernelGGL(row_norm_chain_kernel<4>, grid, dim3(256), 0, st, a2, a1, static_cast<bf16_t*>(x_new_out));
+  return check_launch("row_norm_chain");
+}
+
 // ------------------------------------------------------------------------------------------
 // RoPE table: out[b][l][p] = (cos, sin)(pos_axis(p) * inv_freq[p]); rows l < pad are position 0.
 // pos [n_pos, 3] (t,h,w) f32 is batch independent (the reference expands one grid over the batch);

@@ -185,6 +185,63 @@ def test_full_size_pipeline_properties(hip):
     assert (a[0] - a[1]).abs().max() > 1e-3
 
 
+@pytest.mark.parametrize("D,heads", [(768, 12), (1024, 16)])
+def test_small_batch_decoder_fusions_bitwise_and_against_oracle(hip, D, heads):
+    """The denoising loop at a few hundred rows (skinny.hip): modulate + fc1 + SiLU as one launch, small-M fc2, the last
+    block's gated norm + the final modulate as one row kernel, all replayed as a hipGraph - on a D = 768 / 1024 stand-in
+    with 3 decoder blocks, bf16. Must equal the 128-tile path (modulate as its own launch) bit for bit, with and without
+    graph replay, incl. guidance truncation (pass count changes mid-loop) - and sit at bf16 distance from the f32 oracle."""
+    from diffnext.models.transformers import transformer_nova as TN
+
+    tag = f"w{D}"
+    TN.VIDEO_ENCODERS.register("vit_d1" + tag, TN._vit, depth=1, embed_dim=D, num_heads=heads)
+    TN.IMAGE_ENCODERS.register("vit_d2" + tag, TN._vit, depth=2, embed_dim=D, num_heads=heads)
+    TN.IMAGE_DECODERS.register("mlp_d3" + tag, TN._mlp, depth=3, embed_dim=D)
+    torch.manual_seed(13)
+    model = TN.NOVATransformer3DModel(image_dim=3, image_size=(8 * 16, 10 * 16), image_stride=16, text_token_dim=64,
+                                      text_token_len=8, image_base_size=[8, 10], video_base_size=[1, 4, 5],
+                                      rotary_pos_embed=True, arch=("vit_d1" + tag, "vit_d2" + tag, "mlp_d3" + tag)).eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("bias") or "norm" in n_:
+                p_.add_(torch.randn_like(p_) * 0.05)
+            p_.copy_(p_.bfloat16().float())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    prompts = [(torch.randn(n, 64, generator=g) * 0.5).bfloat16().float() for n in (5, 8, 3)]
+    N = 80
+    order = torch.stack([torch.randperm(N, generator=g) for _ in prompts])
+    noises = torch.randn(5, len(prompts), 3, 8, 10, generator=g)
+    pipe = NOVAPipeline(transformer=model.to(torch.bfloat16).cuda(), scheduler=FlowMatchEulerDiscreteScheduler())
+    kw = dict(prompt_embeds=[p.cuda().bfloat16() for p in prompts], num_inference_steps=5, num_diffusion_steps=4, guidance_scale=4.0,
+              output_type="latent", disable_progress_bar=True, pred_order=order, noise_fn=lambda i: noises[i])
+    runs = {}
+    try:
+        for extra_name, extra in (("plain", {}), ("trunc", {"guidance_trunc": 600.0})):
+            hip.call("nova_debug_force_gemm_tile", 0)
+            hip.set_graphs(True)
+            first = pipe(**kw, **extra).frames
+            replay = pipe(**kw, **extra).frames
+            hip.set_graphs(False)
+            direct = pipe(**kw, **extra).frames
+            hip.call("nova_debug_force_gemm_tile", 128)
+            separate = pipe(**kw, **extra).frames
+            assert torch.equal(first, separate) and torch.equal(replay, separate) and torch.equal(direct, separate), extra_name
+            runs[extra_name] = separate
+    finally:
+        hip.call("nova_debug_force_gemm_tile", 0)
+        hip.set_graphs(True)
+    assert not torch.equal(runs["plain"], runs["trunc"])
+    cfg = O.make_config(3, (8, 10), 1, D, heads, 1, 2, 3, 8, rotary=True)
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 8)
+    u_dist = torch.empty(len(prompts), N, 1)  # uniforms whose argsort is `order` (embeddings.py:265-266)
+    u_dist.scatter_(1, order[..., None], ((torch.arange(N) + 0.5) / N).expand(len(prompts), -1)[..., None].contiguous())
+    assert torch.equal(u_dist.argsort(dim=1)[..., 0], order)
+    ref = O.generate(sd, cfg, prompt, O.cosine_schedule(N, 5), num_diffusion_steps=4, guidance_scale=4.0, u_dist=u_dist,
+                     noises=list(noises))
+    assert rms_rel(runs["plain"].float(), ref) < 4e-2
+
+
 def test_head_dim_96_model_matches_oracle(hip):
     """d48w1536's head_dim (96: RoPE split 12/42/42, 3 value blocks) on a narrow stand-in (D = 384, 4 heads):
     f32 pipeline on the GPU against the oracle (pinned on the 64-wide goldens; the code path is dimension generic)."""

@@ -324,6 +324,26 @@ def test_small_m_gemm_rejects_other_shapes(hip, force_tile):
         hip.gemm_bias_act(a, w, None, 0)
 
 
+@pytest.mark.parametrize("D", [128, 768, 1024, 1536])
+def test_row_norm_chain_equals_two_row_norms(hip, D):
+    """Last block's gated norm + residual and the final layer's modulate as one row pass (nova_row_norm_chain) against
+    nova_row_norm twice: identical bits for h and for the stored x_new."""
+    dtype, rows = torch.bfloat16, 203
+    g, x = rnd(rows, D, dtype=dtype, seed=71), rnd(rows, D, dtype=dtype, seed=72)
+    gamma, beta = rnd(D, seed=73) + 1, rnd(D, seed=74)
+    mod = rnd(rows, 5 * D, dtype=dtype, scale=0.5, seed=75)
+    x_two = hip.row_norm(g, gamma=gamma, beta=beta, mod=mod, gate_off=4 * D, res=x, eps=1e-5)
+    h_two = hip.row_norm(x_two, mod=mod, scale_off=D, shift_off=2 * D, eps=1e-6)
+    x_new, h = torch.empty_like(x), torch.empty_like(x)
+    hip.call("nova_row_norm_chain", hip.ptr(g), hip.ptr(x), hip.ptr(gamma, torch.float32), hip.ptr(beta, torch.float32), hip.ptr(mod),
+             mod.shape[1], 4 * D, D, 2 * D, 1e-5, 1e-6, hip.ptr(x_new), hip.ptr(h), rows, D, hip.stream_ptr())
+    assert torch.equal(x_new, x_two) and torch.equal(h, h_two)
+    h2 = torch.empty_like(x)
+    hip.call("nova_row_norm_chain", hip.ptr(g), hip.ptr(x), hip.ptr(gamma, torch.float32), hip.ptr(beta, torch.float32), hip.ptr(mod),
+             mod.shape[1], 4 * D, D, 2 * D, 1e-5, 1e-6, None, hip.ptr(h2), rows, D, hip.stream_ptr())
+    assert torch.equal(h2, h_two)
+
+
 @pytest.mark.parametrize("rows,D,N", [(1, 768, 768), (37, 768, 768), (256, 768, 768), (300, 1024, 1024), (77, 1024, 2048)])
 def test_adaln_fc1_fused_equals_two_launches(hip, force_tile, rows, D, N):
     """modulate -> fc1 -> SiLU (diffusion_mlp.py:41-47) as ONE launch (LN prologue inside the small-M GEMM) against
