@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NOVA_HIP_VERSION 201 /* 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
+#define NOVA_HIP_VERSION 202 /* 0.2.2: nova_attn_fwd_lse, nova_attn_bwd; 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
 
 typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1 } nova_dtype;
 typedef enum { NOVA_ACT_NONE = 0, NOVA_ACT_GELU_ERF = 1, NOVA_ACT_SILU = 2 } nova_act;
@@ -117,6 +117,18 @@ int nova_rope_table(const float* pos, const long long* ids, float* rope, int nb,
  * transpose(1,2).flatten(2) merge at :64. head_dim 64 (d48w768, d48w1024) and 96 (d48w1536) are built. */
 int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int head_dim,
                   long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, void* stream);
+
+/* Training path of the same attention (bf16, head_dim 64; Lq = Lk = L). q must already be multiplied by
+ * scale * log2(e) (what the fused QKV epilogue does for the generation path); the forward also writes
+ * lse[s, head, l] = log2 sum_j 2^(q~_l . k_j), the backward rebuilds P from it (flash-style, nothing of size L x L is
+ * stored) and returns the gradients w.r.t. the UNSCALED q, k and v. delta[s, head, l] = sum_c dO * O is supplied by the
+ * caller (one elementwise pass). All matrices token-major with row strides as above. Replaces the autograd of
+ * F.scaled_dot_product_attention at vision_transformer.py:63 inside the training forward (transformer_3d.py:79-100). */
+int nova_attn_fwd_lse(const void* q_scaled, const void* k, const void* v, void* o, float* lse, int S, int heads, int L,
+                      long qkv_row_stride, long o_row_stride, void* stream);
+int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
+                  void* dq, void* dk, void* dv, int S, int heads, int L, long qkv_row_stride, long do_row_stride,
+                  long dqkv_row_stride, float scale, void* stream);
 
 /* ---- LayerNorm family -----------------------------------------------------------------------
  * y = LN(in[gather ? gather[r] : r]; eps) [* gamma + beta] [* (1 + mod[r, scale_off..]) +

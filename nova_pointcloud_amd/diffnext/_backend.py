@@ -29,3 +29,13 @@ def hip():
 
 def engine():
     return _module("engine")
+
+
+def autograd():
+    """torch.autograd bindings of the training kernels (nova_pointcloud_amd/autograd.py)."""
+    return _module("autograd")
+
+
+def train_attention_supported(q, attn_mask):
+    """bf16 device tensors [S, heads, L, 64] without a mask: the case the HIP attention backward is built for."""
+    return q.is_cuda and autograd().attention_supported(q, attn_mask)

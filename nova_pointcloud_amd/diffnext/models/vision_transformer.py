@@ -7,7 +7,8 @@ Block :67-92 (POST-norm residual), VisionTransformer :95-146 (MAE-style split: t
 Execution. With device tensors and autograd off, whole block stacks run on libnova_hip.so
 (`nova_vit_blocks_forward`: fused QKV + RoPE GEMM, flash attention reading q / k / v in place, GEMM + GELU, fused
 LayerNorm + residual) and raise if the library is missing; the generation loop bypasses even this and drives the
-stacks from nova_pointcloud_amd/engine.py. With CPU tensors or autograd on (training) the PyTorch definition runs.
+stacks from nova_pointcloud_amd/engine.py. With CPU tensors or autograd on (training) the PyTorch definition runs, with
+the attention itself (forward and backward) on the HIP kernels for bf16 device tensors of head_dim 64.
 """
 from typing import Tuple
 
@@ -87,7 +88,10 @@ class Attention(nn.Module):
             k = self.pe_func(k)
         if self.cache_kv:
             k, v = self._extend_cache(k, v)
-        out = F.scaled_dot_product_attention(q, k, v, attn_mask=self.attn_mask)
+        if torch.is_grad_enabled() and not self.cache_kv and _backend.train_attention_supported(q, self.attn_mask):
+            out = _backend.autograd().attention(q, k, v)  # training on the GPU: HIP flash forward + backward (csrc/attn_bwd.hip)
+        else:
+            out = F.scaled_dot_product_attention(q, k, v, attn_mask=self.attn_mask)
         return self.proj(out.transpose(1, 2).flatten(2))
 
 
