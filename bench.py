@@ -111,7 +111,7 @@ def cpu_baseline(pipe, width, heads, H, W, threads):
                       f"({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {tflops:.3f} TFLOP/s), scaled by FLOPs to 64x25"}
 
 
-PMC_KERNEL = {"attention": "attn_bf16<64>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
+PMC_KERNEL = {"attention": "attn_bf16<64,false>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
               "qkv_gemm_rope": "gemm256p_kernel<bf16,3>"}
 
 

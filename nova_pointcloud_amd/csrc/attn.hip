@@ -35,7 +35,7 @@ constexpr int A_T32 = A_KV * 64;         // 32-wide image (HD = 96 only): 64-byt
 // applied at load (c != 1) for generic callers - and the running max is carried as the C operand of the first
 // QK^T MFMA (a 16-register block holding -m), so the softmax needs no multiply-subtract per score: p = exp2(acc).
 // The block is rewritten only when the deferred-rescale branch fires.
-template <int HD>
+template <int HD, bool LSE>  // LSE: the training forward, which also writes the row log-sum-exp (attn_bwd.hip)
 __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                     const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                                     int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
   const int qrow = q0 + r;
   if (qrow < Lq) {
     // training: log2-domain log-sum-exp of the row's scaled scores, what the backward kernels rebuild P from (attn_bwd.hip)
-    if (lse != nullptr && hh == 0) lse[((size_t)s * heads + head) * Lq + qrow] = m_run + __log2f(l_tot);
+    if (LSE && hh == 0) lse[((size_t)s * heads + head) * Lq + qrow] = m_run + __log2f(l_tot);
     bf16_t* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD;
 #pragma unroll
     for (int dvb = 0; dvb < NDV; ++dvb)
@@ -387,7 +387,7 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (S <= 0 || Lq <= 0) return 0;
   if (hd != 64 && hd != 96) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64 and 96)", hd);
   if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
-  if (lse && dtype != NOVA_BF16) return set_error(NOVA_ERR_ARG, "attn_fwd: the log-sum-exp output is built for the bf16 kernel");
+  if (lse && (dtype != NOVA_BF16 || hd != 64)) return set_error(NOVA_ERR_ARG, "attn_fwd: the log-sum-exp output is built for the bf16 kernel at head_dim 64");
   const int align = dtype == NOVA_BF16 ? 8 : 4;  // 16-byte row alignment for the vector loads
   if (q_rs % align || kv_rs % align || o_rs % align) return set_error(NOVA_ERR_SHAPE, "attn_fwd: row strides must be 16-byte multiples");
   if (kv_ss == 0) kv_ss = (long)Lk * kv_rs;
@@ -401,8 +401,9 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
     const float cl = q_prescaled ? 1.0f : c;
     const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v;
     const int rev = walk_is_reverse() ? 1 : 0;
-    if (hd == 64) hipLaunchKernelGGL(attn_bf16<64>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
-    else hipLaunchKernelGGL(attn_bf16<96>, grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+    if (lse) hipLaunchKernelGGL((attn_bf16<64, true>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+    else if (hd == 64) hipLaunchKernelGGL((attn_bf16<64, false>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+    else hipLaunchKernelGGL((attn_bf16<96, false>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
   } else {
     const float *qq = (const float*)q, *kk = (const float*)k, *vv = (const float*)v;
     if (hd == 64) hipLaunchKernelGGL(attn_f32<64>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c, kv_ss);
