@@ -121,14 +121,15 @@ int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, i
 /* Training path of the same attention (bf16, head_dim 64; Lq = Lk = L). q must already be multiplied by
  * scale * log2(e) (what the fused QKV epilogue does for the generation path); the forward also writes
  * lse[s, head, l] = log2 sum_j 2^(q~_l . k_j), the backward rebuilds P from it (flash-style, nothing of size L x L is
- * stored) and returns the gradients w.r.t. the UNSCALED q, k and v. delta[s, head, l] = sum_c dO * O is supplied by the
- * caller (one elementwise pass). All matrices token-major with row strides as above. Replaces the autograd of
- * F.scaled_dot_product_attention at vision_transformer.py:63 inside the training forward (transformer_3d.py:79-100). */
+ * stored) and returns the gradients w.r.t. the UNSCALED q, k and v; it needs the forward's o for delta[s, head, l] =
+ * sum_c dO * O, which it writes into delta_scratch [S, heads, L] f32 first. All matrices token-major with row strides
+ * as above. Replaces the autograd of F.scaled_dot_product_attention at vision_transformer.py:63 inside the training
+ * forward (transformer_3d.py:79-100). */
 int nova_attn_fwd_lse(const void* q_scaled, const void* k, const void* v, void* o, float* lse, int S, int heads, int L,
                       long qkv_row_stride, long o_row_stride, void* stream);
-int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
-                  void* dq, void* dk, void* dv, int S, int heads, int L, long qkv_row_stride, long do_row_stride,
-                  long dqkv_row_stride, float scale, void* stream);
+int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                  float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, long qkv_row_stride,
+                  long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream);
 
 /* ---- LayerNorm family -----------------------------------------------------------------------
  * y = LN(in[gather ? gather[r] : r]; eps) [* gamma + beta] [* (1 + mod[r, scale_off..]) +

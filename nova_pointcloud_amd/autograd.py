@@ -44,10 +44,11 @@ class NovaAttentionFunction(torch.autograd.Function):
         qt, kt, vt, o, lse = ctx.saved_tensors
         S, L, h, d = qt.shape
         do = d_out.transpose(1, 2).to(torch.bfloat16).contiguous()
-        delta = (do.float() * o.float()).sum(-1).permute(0, 2, 1).contiguous()  # [S, h, L]
+        delta = torch.empty(S, h, L, dtype=torch.float32, device=do.device)  # filled by the library: sum_c dO * O
         dq, dk, dv = torch.empty_like(qt), torch.empty_like(kt), torch.empty_like(vt)
-        hip.call("nova_attn_bwd", qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                 dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), S, h, L, h * d, h * d, h * d, ctx.scale, hip.stream_ptr())
+        hip.call("nova_attn_bwd", qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                 delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), S, h, L, h * d, h * d, h * d, h * d, ctx.scale,
+                 hip.stream_ptr())
         return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)
 
 

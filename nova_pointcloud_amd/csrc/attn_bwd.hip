@@ -278,16 +278,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
   }
 }
 
-int attn_bwd(const void* q, const void* k, const void* v, const void* d_o, const float* lse, const float* delta, void* dq, void* dk,
-             void* dv, int S, int heads, int L, long qkv_rs, long do_rs, long dqkv_rs, float scale, hipStream_t st) {
+// delta[s, head, l] = sum_c dO[s, l, head, c] * O[s, l, head, c]: 8 lanes per (token, head), 16 bytes each
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o,
+                                                         float* __restrict__ delta, int L, int heads, long do_rs, long o_rs, long total) {
+  const long i = (long)blockIdx.x * 32 + (threadIdx.x >> 3);  // (s, l, head) index, head fastest
+  const int part = threadIdx.x & 7;
+  float acc = 0.f;
+  long s = 0;
+  int l = 0, head = 0;
+  if (i < total) {
+    head = (int)(i % heads);
+    const long sl = i / heads;
+    l = (int)(sl % L);
+    s = sl / L;
+    const u4v a = *reinterpret_cast<const u4v*>(d_o + sl * do_rs + head * 64 + part * 8);
+    const u4v b = *reinterpret_cast<const u4v*>(o + sl * o_rs + head * 64 + part * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc += __uint_as_float(a[j] << 16) * __uint_as_float(b[j] << 16) + __uint_as_float(a[j] & 0xffff0000u) * __uint_as_float(b[j] & 0xffff0000u);
+  }
+  acc += dpp_move<0xb1>(acc);   // xor 1
+  acc += dpp_move<0x4e>(acc);   // xor 2
+  acc += dpp_move<0x141>(acc);  // i <-> 7 - i: completes the 8-lane sum
+  if (i < total && part == 0) delta[(s * heads + head) * L + l] = acc;
+}
+
+int attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, void* dq,
+             void* dk, void* dv, int S, int heads, int L, long qkv_rs, long o_rs, long do_rs, long dqkv_rs, float scale, hipStream_t st) {
   if (S <= 0 || L <= 0) return 0;
   if (heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_bwd: bad heads");
-  if (qkv_rs % 8 || do_rs % 8 || dqkv_rs % 8) return set_error(NOVA_ERR_SHAPE, "attn_bwd: row strides must be 16-byte multiples");
+  if (qkv_rs % 8 || do_rs % 8 || dqkv_rs % 8 || o_rs % 8) return set_error(NOVA_ERR_SHAPE, "attn_bwd: row strides must be 16-byte multiples");
   if ((long)L * qkv_rs * 2 > 0x7fffffffL || (long)L * do_rs * 2 > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_bwd: a sequence's rows must span < 2 GiB");
   const int nt = (L + 127) / 128;
   const long blocks = (long)nt * heads * S;
   if (blocks > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_bwd: grid too large");
   const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v, *oo = (const bf16_t*)d_o;
+  const long rows = (long)S * L * heads;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, oo, (const bf16_t*)o, delta, L, heads, do_rs,
+                     o_rs, rows);
   hipLaunchKernelGGL(attn_bwd_dq, dim3((unsigned)blocks), dim3(256), 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dq, L, qkv_rs, do_rs,
                      dqkv_rs, scale, heads, nt);
   hipLaunchKernelGGL(attn_bwd_dkv, dim3((unsigned)blocks), dim3(256), 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dk, (bf16_t*)dv, L,

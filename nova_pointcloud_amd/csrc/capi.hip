@@ -193,12 +193,12 @@ int nova_attn_fwd_lse(const void* q_scaled, const void* k, const void* v, void* 
                   (hipStream_t)stream, true, 0, lse);
 }
 
-int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* d_o, const float* lse, const float* delta,
-                  void* dq, void* dk, void* dv, int S, int heads, int L, long qkv_row_stride, long do_row_stride,
-                  long dqkv_row_stride, float scale, void* stream) {
-  NOVA_REQUIRE(q_scaled && k && v && d_o && lse && delta && dq && dk && dv, NOVA_ERR_ARG, "attn_bwd: null pointer");
-  return attn_bwd(q_scaled, k, v, d_o, lse, delta, dq, dk, dv, S, heads, L, qkv_row_stride, do_row_stride, dqkv_row_stride, scale,
-                  (hipStream_t)stream);
+int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
+                  float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, long qkv_row_stride,
+                  long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream) {
+  NOVA_REQUIRE(q_scaled && k && v && o && d_o && lse && delta_scratch && dq && dk && dv, NOVA_ERR_ARG, "attn_bwd: null pointer");
+  return attn_bwd(q_scaled, k, v, o, d_o, lse, delta_scratch, dq, dk, dv, S, heads, L, qkv_row_stride, o_row_stride, do_row_stride,
+                  dqkv_row_stride, scale, (hipStream_t)stream);
 }
 
 int nova_row_norm(const void* in, void* out, const float* gamma, const float* beta, const void* mod, long mod_ld,
