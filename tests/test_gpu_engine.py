@@ -399,8 +399,8 @@ def test_pipeline_options_on_gpu_match_cpu_module_path(hip):
 
 @pytest.mark.gpu
 def test_training_step_on_gpu_takes_the_torch_path_and_matches_cpu(gold, hip):
-    """with grad enabled the modules must fall back to their torch definition (the HIP
-    kernels have no backward), so `train_video` trains on the GPU unchanged. The random draws of a training step
+    """with grad enabled the modules run their torch definition (f32 here: the HIP attention
+    backward is bf16-only, tests/test_gpu_train_kernels.py), so `train_video` trains on the GPU unchanged. The random draws of a training step
     (mask order, prompt dropout, noise, timesteps) come from device-specific generators, so the GPU step is compared
     with a CPU step of the same model under identical injected draws."""
     import numpy as np
