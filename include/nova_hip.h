@@ -56,7 +56,7 @@ int nova_prof_enable(int on);
 int nova_prof_collect(double* ms, double* work, long long* launches, int slots);
 
 /* Test hook: 0 = automatic choice between the GEMM structures by shape, 16 = the small-M whole-K kernel (bf16, K 768 /
- * 1024; an error for other shapes), 128 / 256 = force the 128x128 or the 256x256 (large-M, persistent) structure,
+ * 1024; an error for other shapes; 161 / 162 / 164 = the same with 16 / 32 / 64 rows per workgroup), 128 / 256 = force the 128x128 or the 256x256 (large-M, persistent) structure,
  * 257 = the 256 structure in its one-tile-per-workgroup form (the fallback of the persistent kernel); all compute
  * bit-identical results (tests/test_gpu_kernels.py compares them). Per calling thread. */
 int nova_debug_force_gemm_tile(int tile);

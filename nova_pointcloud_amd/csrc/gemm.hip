@@ -228,6 +228,12 @@ int gemm_force_tile(int tile) {
     tile = 256;
   }
 #endif
+  if (tile == 161 || tile == 162 || tile == 164) {  // the small-M kernel with 16 / 32 / 64 rows per workgroup
+    skinny_force_row_blocks(tile - 160);
+    tile = 16;
+  } else {
+    skinny_force_row_blocks(0);
+  }
   if (tile != 0 && tile != 16 && tile != 128 && tile != 256 && tile != 257) return -1;
   g_force_tile = tile;  // 257: the 256 tile in its one-tile-per-workgroup form (the fallback of the persistent kernel);
   return 0;             // 16: the small-M kernel of skinny.hip wherever its shapes allow (an error elsewhere)

@@ -70,6 +70,7 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
 
 // ---- skinny.hip: small-M GEMM (bf16, K in {768, 1024}), bit-identical to the tile kernels; optional AdaLN-modulate prologue
 bool skinny_gemm_fits(int M, int N, int K, bool modulate);
+void skinny_force_row_blocks(int rb);  // calling thread: 1 / 2 / 4 = rows per workgroup 16 / 32 / 64 for plain launches, 0 = by rule
 int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                 const RowNormArgs* pro, hipStream_t st);
 int row_norm_chain(const RowNormArgs& a2, const RowNormArgs& a1, void* x_new_out, hipStream_t st);  // rowops.hip, bf16: two chained norms, one pass

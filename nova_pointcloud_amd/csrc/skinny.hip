@@ -23,19 +23,20 @@ namespace nova {
 
 constexpr int SK_R = 16, SK_C = 64;
 
-template <int K, int EPI, bool PRO>
+template <int K, int EPI, bool PRO, int RB>  // RB: 16-row blocks per workgroup (1, 2 or 4; the prologue form is RB = 1 only)
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                           bf16_t* __restrict__ C, int M, int N, const float* __restrict__ bias,
                                                           RowNormArgs pro) {
   constexpr int NS = K / 32;            // MFMA steps
   constexpr int LROW = K * 2 + 16;      // LDS row pitch: +16 B so the 16 rows of a fragment read start in different banks
   constexpr int NIT = (K / 8 + 63) / 64;
-  __shared__ __attribute__((aligned(16))) char smem[SK_R * LROW];
+  constexpr int R = SK_R * RB;          // rows per workgroup
+  __shared__ __attribute__((aligned(16))) char smem[R * LROW];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int ntn = N / SK_C;
   const int tn = blockIdx.x % ntn, tm = blockIdx.x / ntn;
-  const int m0 = tm * SK_R, n0 = tn * SK_C + wid * 16;
+  const int m0 = tm * R, n0 = tn * SK_C + wid * 16;
 
   // ---- weights: lane (fr, fg) holds W[n0 + fr][32 s + 8 fg .. + 8] for every step s
   bf8v wf[NS];
@@ -44,8 +45,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
 #pragma unroll
     for (int s = 0; s < NS; ++s) wf[s] = *reinterpret_cast<const bf8v*>(wp + 32 * s);
   }
-  f4v acc = {0.f, 0.f, 0.f, 0.f};
-  if (bias) acc = *reinterpret_cast<const f4v*>(bias + n0 + 4 * fg);
+  f4v acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] = bias ? *reinterpret_cast<const f4v*>(bias + n0 + 4 * fg) : f4v{0.f, 0.f, 0.f, 0.f};
 
   // ---- activation rows -> LDS; wave w owns rows 4w .. 4w+3 (rows past M repeat row M-1 and are never stored); the
   // loads of all four rows are requested before the first row's reductions
@@ -67,68 +69,101 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
         }
       }
     }
-  } else {
-    u4v raw[4][NIT];
+  } else {  // plain copy: wave w owns rows 4 RB w .. 4 RB (w + 1) - 1, four rows' loads in flight at a time
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int b = 0; b < RB; ++b) {
+      u4v raw[4][NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int d = (it * 64 + lane) * 8;
-        if (d < K) raw[i][it] = *reinterpret_cast<const u4v*>(A + (size_t)min(m0 + wid * 4 + i, M - 1) * K + d);
-      }
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int it = 0; it < NIT; ++it) {
+          const int d = (it * 64 + lane) * 8;
+          if (d < K) raw[i][it] = *reinterpret_cast<const u4v*>(A + (size_t)min(m0 + (wid * RB + b) * 4 + i, M - 1) * K + d);
+        }
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int d = (it * 64 + lane) * 8;
-        if (d < K) *reinterpret_cast<u4v*>(smem + (wid * 4 + i) * LROW + d * 2) = raw[i][it];
-      }
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int d = (it * 64 + lane) * 8;
+          if (d < K) *reinterpret_cast<u4v*>(smem + ((wid * RB + b) * 4 + i) * LROW + d * 2) = raw[i][it];
+        }
+    }
   }
   __syncthreads();
 
-  // ---- K/32 MFMAs, K order
+  // ---- K/32 MFMAs per row block, K order; a weight fragment serves all RB row blocks
   const char* ap = smem + fr * LROW + 16 * fg;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const bf8v af = *reinterpret_cast<const bf8v*>(ap + 64 * s);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af, acc, 0, 0, 0);
-  }
-
-  // ---- epilogue: lane holds out[m0 + fr][n0 + 4 fg .. + 4]
-  const int m = m0 + fr;
-  if (m < M) {
-    if (EPI == 1) {
+  for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = gelu_erf_fast(acc[j]);
-    } else if (EPI == 2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = silu(acc[j]);
+    for (int rb = 0; rb < RB; ++rb) {
+      const bf8v af = *reinterpret_cast<const bf8v*>(ap + rb * 16 * LROW + 64 * s);
+      acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af, acc[rb], 0, 0, 0);
     }
-    const u2v o = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
-    *reinterpret_cast<u2v*>(C + (size_t)m * N + n0 + 4 * fg) = o;
+
+  // ---- epilogue: lane holds out[m0 + 16 rb + fr][n0 + 4 fg .. + 4]
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = m0 + rb * 16 + fr;
+    if (m < M) {
+      f4v v = acc[rb];
+      if (EPI == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+      } else if (EPI == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
+      }
+      const u2v o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      *reinterpret_cast<u2v*>(C + (size_t)m * N + n0 + 4 * fg) = o;
+    }
   }
 }
 
-template <int K, bool PRO>
+template <int K, bool PRO, int RB>
 static void launch_skinny(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, int act,
                           const RowNormArgs& pro, hipStream_t st) {
-  const dim3 grid((unsigned)(((M + SK_R - 1) / SK_R) * (N / SK_C))), block(256);
+  const dim3 grid((unsigned)(((M + SK_R * RB - 1) / (SK_R * RB)) * (N / SK_C))), block(256);
   switch (act) {
-    case 0: hipLaunchKernelGGL((skinny_gemm_kernel<K, 0, PRO>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
-    case 1: hipLaunchKernelGGL((skinny_gemm_kernel<K, 1, PRO>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
-    default: hipLaunchKernelGGL((skinny_gemm_kernel<K, 2, PRO>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+    case 0: hipLaunchKernelGGL((skinny_gemm_kernel<K, 0, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+    case 1: hipLaunchKernelGGL((skinny_gemm_kernel<K, 1, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+    default: hipLaunchKernelGGL((skinny_gemm_kernel<K, 2, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
   }
 }
 
-// Shapes this kernel is built for and worth using on: every row tile re-reads the whole weight matrix and every column
-// tile its 16 activation rows (x 3 with the modulate prologue), all from L2; past ~64 MB of such traffic per launch the
-// 128-tile kernel is faster (tools/skinny_bench.py).
-bool skinny_gemm_fits(int M, int N, int K, bool modulate) {
-  if (M <= 0 || (K != 768 && K != 1024) || N % SK_C != 0) return false;
-  const double row_tiles = (M + SK_R - 1) / SK_R, col_tiles = N / SK_C;
-  const double bytes = row_tiles * (double)N * K * 2.0 + col_tiles * row_tiles * SK_R * (double)K * 2.0 * (modulate ? 3.0 : 1.0);
-  return bytes <= 64.0e6;
+template <int K>
+static void launch_skinny_k(const bf16_t* a, const bf16_t* w, bf16_t* c, int M, int N, const float* bias, int act,
+                            const RowNormArgs* pro, int rb, hipStream_t st) {
+  const RowNormArgs none{};
+  if (pro) launch_skinny<K, true, 1>(a, w, c, M, N, bias, act, *pro, st);
+  else if (rb == 1) launch_skinny<K, false, 1>(a, w, c, M, N, bias, act, none, st);
+  else if (rb == 2) launch_skinny<K, false, 2>(a, w, c, M, N, bias, act, none, st);
+  else launch_skinny<K, false, 4>(a, w, c, M, N, bias, act, none, st);
 }
+
+// Shapes this kernel is built for and worth using on. Every row tile re-reads the whole weight matrix and every column
+// tile its activation rows, all from L2, so the right rows-per-workgroup grows with M (a weight fragment then serves 1, 2
+// or 4 row blocks) until the 128-tile kernel's LDS-shared operands win. Kernel durations under rocprofv3, N = K = D
+// (tools/skinny_bench.py; us at D = 768 | 1024, 128-tile kernel 11-12 | 13-15 throughout):
+//   M <= 256: 16 rows 5.7-5.9 | 6.3-7.3      M 400-512: 32 rows 7.0-7.2 | 8.8      M 800-1024: 64 rows 9.2 | 12.2
+//   M >= 1600: none (14-37 | 21-46).   Modulate + fc1 in one launch (16 rows only): 9.4-9.7 | 10.4-11.7 up to M = 256
+//   against 14.4-15.1 | 18.1-18.3 for row_norm + GEMM; from M = 400 on the two launches are faster.
+// skinny_row_blocks returns 1, 2, 4 (x 16 rows) or 0 = use the tile kernels.
+static thread_local int g_skinny_rb = 0;  // tools / tests: force a row-block count (0 = by the rule above)
+void skinny_force_row_blocks(int rb) { g_skinny_rb = rb; }
+
+int skinny_row_blocks(int M, int N, int K, bool modulate) {
+  if (M <= 0 || (K != 768 && K != 1024) || N % SK_C != 0) return 0;
+  if (g_skinny_rb == 1 || g_skinny_rb == 2 || g_skinny_rb == 4) return modulate ? 1 : g_skinny_rb;
+  const int rb = M <= 320 ? 1 : (modulate ? 0 : M <= 640 ? 2 : M <= 1100 ? 4 : 0);
+  if (rb == 0) return 0;
+  // wide outputs (N >> K: the AdaLN projection, fc1 of a ViT block): the weight re-reads of all row tiles must stay a few
+  // tens of MB of L2 traffic, or the tile kernels' once-per-128-rows weight reads win
+  const double weight_bytes = (double)((M + SK_R * rb - 1) / (SK_R * rb)) * N * K * 2.0;
+  return weight_bytes <= 64.0e6 ? rb : 0;
+}
+
+bool skinny_gemm_fits(int M, int N, int K, bool modulate) { return skinny_row_blocks(M, N, K, modulate) != 0; }
 
 // `pro` null: plain GEMM on A. Otherwise pro->in / mod / scale_off / shift_off / eps describe the AdaLN modulate whose
 // result is the A operand (pro->out, gamma, res, gate and gather are not used: the m1 form of diffusion_mlp.py:41-43).
@@ -144,14 +179,10 @@ int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int 
   const bf16_t* a = static_cast<const bf16_t*>(A);
   const bf16_t* w = static_cast<const bf16_t*>(W);
   bf16_t* c = static_cast<bf16_t*>(out);
-  const RowNormArgs none{};
-  if (K == 768) {
-    if (pro) launch_skinny<768, true>(a, w, c, M, N, bias, act, *pro, st);
-    else launch_skinny<768, false>(a, w, c, M, N, bias, act, none, st);
-  } else {
-    if (pro) launch_skinny<1024, true>(a, w, c, M, N, bias, act, *pro, st);
-    else launch_skinny<1024, false>(a, w, c, M, N, bias, act, none, st);
-  }
+  int rb = pro ? 1 : skinny_row_blocks(M, N, K, false);
+  if (rb == 0) rb = 1;  // forced onto a shape the traffic rule would not pick (nova_debug_force_gemm_tile(16))
+  if (K == 768) launch_skinny_k<768>(a, w, c, M, N, bias, act, pro, rb, st);
+  else launch_skinny_k<1024>(a, w, c, M, N, bias, act, pro, rb, st);
   return check_launch("skinny_gemm");
 }
 

@@ -296,7 +296,7 @@ def test_gemm_256_tile_bitwise_equals_128_tile(hip, force_tile, form, dtype, M, 
 
 
 @pytest.mark.parametrize("M,N,K,act", [(1, 768, 768, 0), (16, 768, 768, 2), (200, 768, 768, 2), (257, 3072, 768, 1), (999, 1024, 1024, 2),
-                                        (130, 4096, 1024, 1), (64, 64, 1024, 0)])
+                                        (130, 4096, 1024, 1), (64, 64, 1024, 0), (1500, 1024, 1024, 2), (3000, 768, 768, 0)])
 def test_small_m_gemm_bitwise_equals_tile_kernels(hip, force_tile, M, N, K, act):
     """skinny.hip (whole-K workgroups, weights global -> registers) against the 128-tile kernel, bit for bit: the kernel
     picked by the row count must never show in the result (batch / lane splits of the engine rely on it)."""
@@ -313,6 +313,9 @@ def test_small_m_gemm_bitwise_equals_tile_kernels(hip, force_tile, M, N, K, act)
     full = a.float() @ w.float().T + bias
     full = [lambda x: x, torch.nn.functional.gelu, torch.nn.functional.silu][act](full)
     assert relerr(out, full) < tol(dtype)
+    for code in (161, 162, 164):  # 16 / 32 / 64 rows per workgroup: a weight fragment serves 1 / 2 / 4 row blocks
+        force_tile(code)
+        assert torch.equal(out, hip.gemm_bias_act(a, w, bias, act)), code
     force_tile(0)  # the automatic choice (small-M kernel at these sizes where it pays) gives the same bits again
     assert torch.equal(out, hip.gemm_bias_act(a, w, bias, act))
 
