@@ -473,6 +473,51 @@ def test_multi_frame_bf16_and_lanes(vgold, hip):
         assert torch.equal(a, b)
 
 
+def test_multi_frame_three_pass_at_full_width_matches_oracle(hip):
+    """The multi-frame branches at the headline WIDTH (D = 1024, 16 heads, 512-point frames; 2 + 2 + 2 blocks so the oracle
+    stays in seconds): KV-cached conditioning encoder with Lq != Lk, frame mixer, motion tokens, 3-pass image guidance with
+    truncation - f32 from one seed against the oracle (which the D = 128 fixtures of the reference's generate_video pin),
+    bf16 with the draws injected."""
+    from diffnext.models.transformers import transformer_nova as TN
+
+    D, heads, H, W, T = 1024, 16, 16, 32, 2
+    TN.VIDEO_ENCODERS.register("vit_d2w1024v", TN._vit, depth=2, embed_dim=D, num_heads=heads)
+    TN.IMAGE_ENCODERS.register("vit_d2w1024i", TN._vit, depth=2, embed_dim=D, num_heads=heads)
+    TN.IMAGE_DECODERS.register("mlp_d2w1024", TN._mlp, depth=2, embed_dim=D)
+    torch.manual_seed(17)
+    model = TN.NOVATransformer3DModel(image_dim=3, image_size=(H * 16, W * 16), image_stride=16, text_token_dim=64, text_token_len=8,
+                                      image_base_size=[H, W], video_base_size=[T, H // 2, W // 2], video_mixer_rank=-1,
+                                      rotary_pos_embed=True, arch=("vit_d2w1024v", "vit_d2w1024i", "mlp_d2w1024")).eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("bias") or "mixer" in n_:
+                p_.add_(torch.randn_like(p_) * 0.05)
+            p_.copy_(p_.bfloat16().float())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(6)
+    prompts = [(torch.randn(n, 64, generator=g) * 0.5).bfloat16().float() for n in (6, 4)]
+    B, N, K, S = len(prompts), H * W, 3, 3
+    cfg = O.make_config(3, (H, W), 1, D, heads, 2, 2, 2, 8, rotary=True, video_base_t=T)
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 8)
+    extra = dict(image_guidance_scale=1.5, guidance_trunc=400.0)
+    ref = O.generate(sd, cfg, prompt, O.cosine_schedule(N, K), num_diffusion_steps=S, guidance_scale=4.0,
+                     generator=torch.Generator().manual_seed(8), max_latent_length=T, motion_flow=[5] * B, **extra)
+    kw = dict(num_inference_steps=K, num_diffusion_steps=S, guidance_scale=4.0, max_latent_length=T, output_type="latent",
+              disable_progress_bar=True, motion_flow=5, **extra)  # the pipeline takes one flow value per call (pipeline_nova.py:137)
+    pipe = NOVAPipeline(transformer=model.cuda(), scheduler=FlowMatchEulerDiscreteScheduler())
+    x = pipe(prompt_embeds=[p.cuda() for p in prompts], generator=torch.Generator().manual_seed(8), **kw).frames
+    assert x.shape == ref.shape == (B, 3, T, H, W)
+    assert rel(x, ref) < 1e-3 and rel(x, ref) < 2e-4, rel(x, ref)
+    # bf16: replay the same draws (one uniform [B, N, 1], then one normal per AR step of every frame)
+    g2 = torch.Generator().manual_seed(8)
+    order = torch.empty(B, N, 1).uniform_(generator=g2).argsort(dim=1)[..., 0]
+    steps = len([v for v in O.cosine_schedule(N, K) if v > 0])
+    noises = [torch.empty(B, 3, H, W).normal_(generator=g2) for _ in range(T * steps)]
+    pipe16 = NOVAPipeline(transformer=model.to(torch.bfloat16), scheduler=FlowMatchEulerDiscreteScheduler())
+    x16 = pipe16(prompt_embeds=[p.cuda().bfloat16() for p in prompts], pred_order=order, noise_fn=lambda i: noises[i], **kw).frames
+    assert rms_rel(x16.float(), ref) < 4e-2, rms_rel(x16.float(), ref)
+
+
 def test_three_pass_rejects_both_scales(vgold, hip):
     with pytest.raises(ValueError):
         video_call(vgold, "cuda", torch.float32, image_guidance_scale=1.0, spatiotemporal_guidance_scale=1.0)
