@@ -14,7 +14,10 @@ import torch.distributed as dist
 class GradientReducer(object):
     def __init__(self, params, bucket_mb=256.0, group=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # collectives run whenever a process group exists - also with one rank (a single-GPU torchrun launch then still
+        # goes through RCCL: broadcast, bucketed all_reduce, scalar all_reduce), never without one
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
         self.params = [p for p in params if p.requires_grad]
         self.buckets, cur, cur_bytes = [], [], 0
         limit = int(bucket_mb * 2 ** 20)
@@ -27,7 +30,7 @@ class GradientReducer(object):
             cur_bytes += nbytes
         if cur:
             self.buckets.append(cur)
-        if self.world > 1:
+        if self.active:
             with torch.no_grad():
                 for p in params:  # every rank starts from rank 0's weights (frozen parameters included)
                     dist.broadcast(p.data, src=0, group=group)
@@ -35,7 +38,7 @@ class GradientReducer(object):
     @torch.no_grad()
     def sync_gradients(self):
         """Average the accumulated gradients over the ranks, bucket by bucket (parameters without a gradient count as 0)."""
-        if self.world == 1:
+        if not self.active:
             return
         for bucket in self.buckets:
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
@@ -52,7 +55,7 @@ class GradientReducer(object):
 
     def gather_mean(self, value):
         """Mean of a scalar over the ranks (the `accelerator.gather(v).mean()` of run_model)."""
-        if self.world == 1:
+        if not self.active:
             return float(value)
         t = torch.as_tensor(float(value), dtype=torch.float64, device=self.params[0].device if self.params else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

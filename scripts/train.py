@@ -70,8 +70,12 @@ def main(argv=None):
     device = torch.device("cuda", local) if use_gpu else torch.device("cpu")
     if use_gpu:
         torch.cuda.set_device(local)
-    if world > 1:
+    # one process per GPU under torchrun; a single-rank launch under torchrun also goes through the process group, so the
+    # RCCL path (bucketed all_reduce of the gradients, barrier) is exercised on a one-GPU box as well
+    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl" if use_gpu else "gloo", rank=rank, world_size=world, **({"device_id": device} if use_gpu else {}))
     logging.basicConfig(level=logging.INFO if rank == 0 else logging.WARNING, format="%(asctime)s %(message)s")
     logger = logging.getLogger("diffnext.train")
@@ -101,14 +105,38 @@ def main(argv=None):
         os.makedirs(exp.get("output_dir", "."), exist_ok=True)
         with open(os.path.join(exp.get("output_dir", "."), "config.yaml"), "w") as f:
             yaml.safe_dump(config, f)
+    attn_calls = _count_hip_attention()
     history = trainer.train_loop()
     if trainer.ema:
         trainer.ema.update(trainer.model)
     path = trainer.save()
-    if world > 1:
+    if rank == 0 and os.environ.get("NOVA_TRAIN_LOG_JSON"):  # machine-readable summary for the launch tests
+        import json
+
+        with open(os.environ["NOVA_TRAIN_LOG_JSON"], "w") as f:
+            json.dump({"world": world, "backend": dist.get_backend() if distributed else None, "dtype": str(dtype),
+                       "loss": [h["metrics"]["loss"] for h in history], "hip_attention_calls": attn_calls[0]}, f)
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     return history, path
+
+
+def _count_hip_attention():
+    """Counts calls of the HIP attention (nova_pointcloud_amd.autograd) during training; [0] stays 0 on the torch path."""
+    calls = [0]
+    try:
+        from nova_pointcloud_amd import autograd as A
+    except Exception:  # CPU-only box without the library: nothing to count
+        return calls
+    orig = A.NovaAttentionFunction.apply
+
+    def counted(*a):
+        calls[0] += 1
+        return orig(*a)
+
+    A.NovaAttentionFunction.apply = staticmethod(counted)
+    return calls
 
 
 if __name__ == "__main__":

@@ -130,3 +130,26 @@ def test_bf16_training_step_with_hip_attention_matches_torch_attention(hip):
         assert cos > 0.98, (name, cos)
         worst = max(worst, 1 - cos)
     print(f"\n[train-attn] loss hip {loss_hip:.5f} torch {loss_pt:.5f}; worst 1 - cos over {len(g_pt)} gradients {worst:.2e}")
+
+
+def test_train_script_one_rank_under_torchrun_bf16_on_rccl(hip, tmp_path):
+    """`scripts/train.py` as the reference launches it - one process per GPU under torchrun - on this box's one GPU:
+    NOVA-d48w768 random-init (the config's architecture), bf16, 64-point synthetic samples, 3 steps. The process group is
+    RCCL ("nccl"), so the weight broadcast, the bucketed gradient all_reduce and the loss all_reduce run on the device;
+    the ViT blocks take the HIP attention forward + backward (bf16, head_dim 64). Checks the loss log and the checkpoint."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(PKG)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([PKG, root, os.environ.get("PYTHONPATH", "")]), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               NOVA_TRAIN_LOG_JSON=str(tmp_path / "history.json"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node=1", "--local-addr", "127.0.0.1",
+           os.path.join(root, "scripts", "train.py"), "--config", os.path.join(root, "configs", "train_pointcloud_tiny.yaml"),
+           f"experiment.output_dir={tmp_path}", "training.max_train_steps=3", "training.mixed_precision=bf16", "train_dataloader.batch_size=4"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    history = json.load(open(tmp_path / "history.json"))
+    assert history["world"] == 1 and history["backend"] == "nccl" and history["dtype"] == "torch.bfloat16"
+    assert len(history["loss"]) == 3 and all(0 < v < 10 for v in history["loss"])
+    assert history["hip_attention_calls"] > 0
+    assert os.path.isdir(os.path.join(str(tmp_path), "checkpoints", "checkpoint-3", "transformer"))
