@@ -171,7 +171,10 @@ def main():
         device = torch.device("cuda", local)
     torch.set_num_threads(max(1, host_cores() // world))  # N ranks build N CPU-initialised copies of the weights
     dist = None
-    if world > 1:
+    # one rank per GPU under torch.distributed.run; a one-rank launch under it also goes through the process group (RCCL
+    # init, barrier, all_gather of the points, max-over-ranks of the time), a plain `python bench.py` does not
+    distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -203,7 +206,7 @@ def main():
                                 num_diffusion_steps=args.diffusion_steps, guidance_scale=5, generator=gen, **call_extra, **extra)
 
     def fence():
-        if world > 1:
+        if distributed:
             dist.barrier()
         sync()
 
@@ -235,7 +238,7 @@ def main():
         hip.prof_enable(False)
     assert torch.isfinite(pts).all(), "non-finite points generated"
     assert pts.shape[0] == world * B, "gathered point sets do not cover the global batch"
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -251,7 +254,7 @@ def main():
         mfma = {k: v for k, v in fams.items() if k != "row_norm"}
         if dry:
             print(json.dumps({"dry_run": True, "n_gpus": world, "points": list(pts.shape), "ms_per_step": round(elapsed / args.steps * 1e3, 2)}), flush=True)
-            if world > 1:
+            if distributed:
                 dist.barrier()
                 dist.destroy_process_group()
             return
@@ -287,7 +290,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(pipe, width, heads, H, W, threads=host_cores())
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

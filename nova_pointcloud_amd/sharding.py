@@ -31,7 +31,7 @@ def gather_points(points, group=None):
     """
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized():  # with a process group the exchange runs, also for one rank
         return points
     world = dist.get_world_size(group)
     points = points.contiguous()

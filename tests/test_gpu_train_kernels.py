@@ -153,3 +153,25 @@ def test_train_script_one_rank_under_torchrun_bf16_on_rccl(hip, tmp_path):
     assert len(history["loss"]) == 3 and all(0 < v < 10 for v in history["loss"])
     assert history["hip_attention_calls"] > 0
     assert os.path.isdir(os.path.join(str(tmp_path), "checkpoints", "checkpoint-3", "transformer"))
+
+
+def test_bench_launch_contract_one_rank_on_rccl(hip):
+    """The driver's N > 1 launch line (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`) with N = 1 on this box's GPU: RCCL process group, barrier-bracketed
+    timing, all_gather of the generated point sets, max-over-ranks time, ONE JSON line from rank 0 (reduced AR / diffusion
+    step counts; the contract, not the number, is under test)."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(PKG)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--workload", "d48w768_1024pts_b8", "--ar-steps", "6", "--diffusion-steps", "3", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["steps"] == 1 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["config"]["global_batch"] == 8 and "roofline" in rec
