@@ -14,6 +14,7 @@ from . import hip
 
 _ENABLED = os.environ.get("NOVA_TRAIN_ATTN", "1") != "0"  # read once
 LOG2E = 1.4426950408889634
+stats = {"attention_calls": 0}  # forward calls of the HIP attention in this process (launch tests and logs read it)
 
 
 def attention_supported(q, attn_mask=None):
@@ -27,6 +28,7 @@ class NovaAttentionFunction(torch.autograd.Function):
         if k.shape != q.shape or v.shape != q.shape:
             raise ValueError("nova attention (training) is self-attention: q, k, v must share one shape [S, heads, L, 64]")
         hip.load()
+        stats["attention_calls"] += 1
         scale = 1.0 / math.sqrt(d)
         # token-major copies [S, L, h, d]; q pre-scaled into the exp2 domain exactly as the generation path's QKV epilogue does
         qt = (q.transpose(1, 2).float() * (scale * LOG2E)).to(torch.bfloat16).contiguous()

@@ -105,7 +105,6 @@ def main(argv=None):
         os.makedirs(exp.get("output_dir", "."), exist_ok=True)
         with open(os.path.join(exp.get("output_dir", "."), "config.yaml"), "w") as f:
             yaml.safe_dump(config, f)
-    attn_calls = _count_hip_attention()
     history = trainer.train_loop()
     if trainer.ema:
         trainer.ema.update(trainer.model)
@@ -115,28 +114,18 @@ def main(argv=None):
 
         with open(os.environ["NOVA_TRAIN_LOG_JSON"], "w") as f:
             json.dump({"world": world, "backend": dist.get_backend() if distributed else None, "dtype": str(dtype),
-                       "loss": [h["metrics"]["loss"] for h in history], "hip_attention_calls": attn_calls[0]}, f)
+                       "loss": [h["metrics"]["loss"] for h in history], "hip_attention_calls": _hip_attention_calls()}, f)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     return history, path
 
 
-def _count_hip_attention():
-    """Counts calls of the HIP attention (nova_pointcloud_amd.autograd) during training; [0] stays 0 on the torch path."""
-    calls = [0]
-    try:
-        from nova_pointcloud_amd import autograd as A
-    except Exception:  # CPU-only box without the library: nothing to count
-        return calls
-    orig = A.NovaAttentionFunction.apply
 
-    def counted(*a):
-        calls[0] += 1
-        return orig(*a)
-
-    A.NovaAttentionFunction.apply = staticmethod(counted)
-    return calls
+def _hip_attention_calls():
+    """Forward calls of the HIP training attention in this process (0 on the PyTorch path / without the library)."""
+    mod = sys.modules.get("nova_pointcloud_amd.autograd")
+    return mod.stats["attention_calls"] if mod is not None else 0
 
 
 if __name__ == "__main__":
