@@ -13,8 +13,7 @@
 //   attn_bwd_dkv: a workgroup owns 128 KEY rows (K and V fragments in registers) and streams Q~ / dO. S = Q~ K^T puts a key
 //                 on every lane and 16 queries in a lane's registers (their lse / delta come from the tile's LDS copy);
 //                 P and dS (cast) are the B operands of dV^T += dO^T P and dK^T += Q~^T dS, dO^T / Q~^T by transposing
-//                 reads. Every tile is staged twice, once in the image the row-fragment reads want and once in the
-//                 image the transposing reads want (both conflict-free, the forward's K and V images).
+//                 reads of the same LDS image the row fragments come from.
 // S and dP are computed in both kernels (7 MFMA products instead of the minimal 5): the price of having no cross-workgroup
 // sum and of running every product in the orientation whose accumulator is directly the next product's operand.
 #include "common.h"
@@ -26,18 +25,17 @@ constexpr int B_T = 64;            // streamed rows per tile
 constexpr int B_IMG = B_T * 128;   // one 64 x 64 bf16 image, 8 KiB
 constexpr float LN2 = 0.6931471805599453f;
 
-// Stage rows [t0, t0 + 64) of a token-major matrix (row stride rowB bytes, this head's 128-byte slice) into two LDS
-// images: `plain` (chunk c of row r at c ^ ((r >> 1) & 7): conflict-free ds_read_b128 of row fragments) and `tr`
-// (chunk c at c ^ (((r >> 1) & 1) << 2): conflict-free ds_read_b64_tr_b16). Wave w moves pieces 2w, 2w+1 (8 rows each).
-// Rows past `last` re-read row `last` (callers mask them).
-__device__ __forceinline__ void stage_pair(const char* base, uint32_t rowB, int t0, int last, char* plain, char* tr, int wid, int lane) {
+// Stage rows [t0, t0 + 64) of a token-major matrix (row stride rowB bytes, this head's 128-byte slice) into an LDS image
+// with chunk c of row r at c ^ ((r >> 1) & 7): conflict-free ds_read_b128 of row fragments, and the transposing
+// ds_read_b64_tr_b16 reads of the same image run as fast as from an image of their own (measured: staging every tile a
+// second time in the forward's V-image swizzle was 1-3 % slower). Wave w moves pieces 2w, 2w+1 (8 rows each). Rows past
+// `last` re-read row `last` (callers mask them).
+__device__ __forceinline__ void stage_tile(const char* base, uint32_t rowB, int t0, int last, char* img, int wid, int lane) {
   const int scp = lane & 7;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (wid * 2 + i) * 8 + (lane >> 3);
-    const uint32_t src = (uint32_t)min(t0 + row, last) * rowB;
-    if (plain) glds16(base, src + (uint32_t)((scp ^ ((row >> 1) & 7)) << 4), plain + (wid * 2 + i) * 1024);
-    if (tr) glds16(base, src + (uint32_t)((scp ^ (((row >> 1) & 1) << 2)) << 4), tr + (wid * 2 + i) * 1024);
+    glds16(base, (uint32_t)min(t0 + row, last) * rowB + (uint32_t)((scp ^ ((row >> 1) & 7)) << 4), img + (wid * 2 + i) * 1024);
   }
 }
 
@@ -53,8 +51,8 @@ __device__ __forceinline__ bf8v frag_tr(const char* img, int cb, int rb, int j, 
   const int col = cb * 32 + 16 * t_gp + 4 * t_p;
   const int chunk = col >> 3, within = (t_p & 1) * 8;
   const int row0 = rb * 32 + 16 * j + 4 * hh + t_qr, row1 = row0 + 8;
-  const char* a0 = img + row0 * 128 + ((chunk ^ (((row0 >> 1) & 1) << 2)) << 4) + within;
-  const char* a1 = img + row1 * 128 + ((chunk ^ (((row1 >> 1) & 1) << 2)) << 4) + within;
+  const char* a0 = img + row0 * 128 + ((chunk ^ ((row0 >> 1) & 7)) << 4) + within;
+  const char* a1 = img + row1 * 128 + ((chunk ^ ((row1 >> 1) & 7)) << 4) + within;
   const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
   const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a1);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -86,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       bf16_t* __restrict__ dq, int L, long qkv_rs, long do_rs, long dq_rs,
                                                       float scale, int heads, int nq) {
-  constexpr int BUF = 3 * B_IMG;  // [K plain | K tr | V plain]
+  constexpr int BUF = 2 * B_IMG;  // [K | V]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
   const uint32_t rowB = (uint32_t)qkv_rs * 2u;
   auto stage = [&](int buf, int kt) {
     char* b = smem + buf * BUF;
-    stage_pair(kb_, rowB, kt * B_T, L - 1, b, b + B_IMG, wid, lane);
-    stage_pair(vb_, rowB, kt * B_T, L - 1, b + 2 * B_IMG, nullptr, wid, lane);
+    stage_tile(kb_, rowB, kt * B_T, L - 1, b, wid, lane);
+    stage_tile(vb_, rowB, kt * B_T, L - 1, b + B_IMG, wid, lane);
   };
 
   f16v dqt[2] = {zero16(), zero16()};  // dQ^T [d x q], two 32-row d blocks
@@ -128,8 +126,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
     __syncthreads();
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     const char* tk = smem + (kt & 1) * BUF;
-    const char* tkt = tk + B_IMG;
-    const char* tv = tk + 2 * B_IMG;
+    const char* tv = tk + B_IMG;
     bf8v dsb[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -154,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tkt, db, kb, j, lane), dsb[kb][j], dqt[db], 0, 0, 0);  // dQ^T += K^T dS^T
+          dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tk, db, kb, j, lane), dsb[kb][j], dqt[db], 0, 0, 0);  // dQ^T += K^T dS^T
   }
 
   if (q0 + r < L) {
@@ -178,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
                                                        const float* __restrict__ lse, const float* __restrict__ delta,
                                                        bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int L, long qkv_rs,
                                                        long do_rs, long dkv_rs, int heads, int nk) {
-  constexpr int BUF = 4 * B_IMG + 2 * B_T * 4;  // [Q plain | Q tr | dO plain | dO tr | lse | delta]
+  constexpr int BUF = 2 * B_IMG + 2 * B_T * 4;  // [Q | dO | lse | delta]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -206,12 +203,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
   const uint32_t qB = (uint32_t)qkv_rs * 2u, oB = (uint32_t)do_rs * 2u;
   auto stage = [&](int buf, int qt) {
     char* b = smem + buf * BUF;
-    stage_pair(qb_, qB, qt * B_T, L - 1, b, b + B_IMG, wid, lane);
-    stage_pair(ob_, oB, qt * B_T, L - 1, b + 2 * B_IMG, b + 3 * B_IMG, wid, lane);
+    stage_tile(qb_, qB, qt * B_T, L - 1, b, wid, lane);
+    stage_tile(ob_, oB, qt * B_T, L - 1, b + B_IMG, wid, lane);
     if (tid < 2 * B_T) {  // the tile's lse | delta (plain stores: visible after the barrier that opens the tile)
       const int i = tid & (B_T - 1);
       const int row = min(qt * B_T + i, L - 1);
-      reinterpret_cast<float*>(b + 4 * B_IMG)[tid] = tid < B_T ? lse_b[row] : del_b[row];
+      reinterpret_cast<float*>(b + 2 * B_IMG)[tid] = tid < B_T ? lse_b[row] : del_b[row];
     }
   };
 
@@ -223,10 +220,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
     __syncthreads();
     if (qt + 1 < nqt) stage((qt + 1) & 1, qt + 1);
     const char* tq = smem + (qt & 1) * BUF;
-    const char* tqt = tq + B_IMG;
-    const char* to = tq + 2 * B_IMG;
-    const char* tot = tq + 3 * B_IMG;
-    const float* tl = reinterpret_cast<const float*>(tq + 4 * B_IMG);
+    const char* to = tq + B_IMG;
+    const float* tl = reinterpret_cast<const float*>(tq + 2 * B_IMG);
     bf8v pb[2][2], dsb[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -257,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tot, db, qb, j, lane), pb[qb][j], dvt[db], 0, 0, 0);   // dV^T += dO^T P
-          dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tqt, db, qb, j, lane), dsb[qb][j], dkt[db], 0, 0, 0);  // dK^T += Q~^T dS
+          dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(to, db, qb, j, lane), pb[qb][j], dvt[db], 0, 0, 0);   // dV^T += dO^T P
+          dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr(tq, db, qb, j, lane), dsb[qb][j], dkt[db], 0, 0, 0);  // dK^T += Q~^T dS
         }
   }
 

@@ -3,15 +3,16 @@
 // (reference diffnext/models/diffusion_mlp.py:31-36,41-47: DiffusionBlock = AdaLN modulate -> fc1 -> SiLU -> fc2 -> gated
 // norm; 25 denoising steps x 6 blocks per AR step, transformer_3d.py:102-113). At batch 8 these GEMMs have a few hundred
 // rows: the 128x128-tile kernel then runs 12-48 workgroups through a 12-16 deep chain of barrier-separated K-tiles
-// (14.5 us per launch, 25 TFLOP/s) and the AdaLN modulate ahead of fc1 is a launch of its own (6 us for 256 rows).
+// (11-14 us per launch) and the AdaLN modulate ahead of fc1 is a launch of its own (4-6 us for 256 rows).
 //
-// Structure: a workgroup owns 16 rows x 64 columns and the WHOLE K extent (K in {768, 1024}: d48w768 / d48w1024).
+// Structure: a workgroup owns 16 x RB rows (RB = 1, 2, 4 as M grows: a weight fragment then serves RB row blocks) x 64
+// columns and the WHOLE K extent (K in {768, 1024}: d48w768 / d48w1024).
 //   * the weight fragments of a wave's 16 columns go global -> registers directly, all K/32 of them requested before
 //     anything else (each element is used by exactly one wave: staging it through LDS would buy nothing);
-//   * the 16 activation rows are written to LDS once, either copied or - PRO - produced by the AdaLN modulate
+//   * the activation rows are written to LDS once, either copied or - PRO, 16 rows - produced by the AdaLN modulate
 //     LN(x)(1 + scale) + shift itself (rownorm.h: the arithmetic of row_norm_kernel, one wave per row), so the
 //     modulate launch disappears; every column tile recomputes its 16 rows, which is cheap next to a launch;
-//   * one barrier, then K/32 MFMAs per wave in K order on one accumulator that starts at the bias.
+//   * one barrier, then K/32 MFMAs per wave and row block in K order on an accumulator that starts at the bias.
 // Same MFMA (v_mfma_f32_16x16x32_bf16, weight fragment as A operand), same K order, same lane <-> k-slice placement,
 // same epilogue functions as gemm_kernel / gemm256: results are BIT-IDENTICAL to the large-tile kernels, so the
 // choice of kernel by M never shows in the output (batch and lane splits stay exact; tests compare bit for bit).

@@ -19,7 +19,6 @@ Data layout in HBM (all row-major, one token per row):
                mask [B, N] float32, generation order [B, N] int64
 """
 import ctypes
-
 import os
 
 import numpy as np

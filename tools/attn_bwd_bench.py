@@ -7,7 +7,10 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from nova_pointcloud_amd import autograd as A  # noqa: E402
+from nova_pointcloud_amd import autograd as A, hip  # noqa: E402
+
+if os.environ.get("NOVA_HIP_LIB"):  # A/B another build of the library
+    hip._LIB_PATH = os.environ["NOVA_HIP_LIB"]
 from microbench import timeit  # noqa: E402
 
 for (S, h, L) in ((16, 16, 2560), (16, 12, 1280), (4, 16, 2560)):
