@@ -118,7 +118,7 @@ int nova_rope_table(const float* pos, const long long* ids, float* rope, int nb,
 int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int head_dim,
                   long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, void* stream);
 
-/* Training path of the same attention (bf16, head_dim 64; Lq = Lk = L). q must already be multiplied by
+/* Training path of the same attention (bf16, head_dim 64 or 96; Lq = Lk = L). q must already be multiplied by
  * scale * log2(e) (what the fused QKV epilogue does for the generation path); the forward also writes
  * lse[s, head, l] = log2 sum_j 2^(q~_l . k_j), the backward rebuilds P from it (flash-style, nothing of size L x L is
  * stored) and returns the gradients w.r.t. the UNSCALED q, k and v; it needs the forward's o for delta[s, head, l] =
@@ -126,10 +126,10 @@ int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, i
  * as above. Replaces the autograd of F.scaled_dot_product_attention at vision_transformer.py:63 inside the training
  * forward (transformer_3d.py:79-100). */
 int nova_attn_fwd_lse(const void* q_scaled, const void* k, const void* v, void* o, float* lse, int S, int heads, int L,
-                      long qkv_row_stride, long o_row_stride, void* stream);
+                      int head_dim, long qkv_row_stride, long o_row_stride, void* stream);
 int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                  float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, long qkv_row_stride,
-                  long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream);
+                  float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, int head_dim,
+                  long qkv_row_stride, long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream);
 
 /* ---- LayerNorm family -----------------------------------------------------------------------
  * y = LN(in[gather ? gather[r] : r]; eps) [* gamma + beta] [* (1 + mod[r, scale_off..]) +

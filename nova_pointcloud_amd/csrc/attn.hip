@@ -387,7 +387,7 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (S <= 0 || Lq <= 0) return 0;
   if (hd != 64 && hd != 96) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64 and 96)", hd);
   if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
-  if (lse && (dtype != NOVA_BF16 || hd != 64)) return set_error(NOVA_ERR_ARG, "attn_fwd: the log-sum-exp output is built for the bf16 kernel at head_dim 64");
+  if (lse && dtype != NOVA_BF16) return set_error(NOVA_ERR_ARG, "attn_fwd: the log-sum-exp output is built for the bf16 kernel");
   const int align = dtype == NOVA_BF16 ? 8 : 4;  // 16-byte row alignment for the vector loads
   if (q_rs % align || kv_rs % align || o_rs % align) return set_error(NOVA_ERR_SHAPE, "attn_fwd: row strides must be 16-byte multiples");
   if (kv_ss == 0) kv_ss = (long)Lk * kv_rs;
@@ -401,7 +401,8 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
     const float cl = q_prescaled ? 1.0f : c;
     const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v;
     const int rev = walk_is_reverse() ? 1 : 0;
-    if (lse) hipLaunchKernelGGL((attn_bf16<64, true>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+    if (lse && hd == 64) hipLaunchKernelGGL((attn_bf16<64, true>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+    else if (lse) hipLaunchKernelGGL((attn_bf16<96, true>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
     else if (hd == 64) hipLaunchKernelGGL((attn_bf16<64, false>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
     else hipLaunchKernelGGL((attn_bf16<96, false>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
   } else {

@@ -1,4 +1,4 @@
-// NOVA training path: backward of the non-causal self-attention of attn.hip
+// NOVA training path: backward of the non-causal self-attention of attn.hip (bf16, head_dim 64 and 96)
 //   o = softmax(q k^T * scale) v   ->   dq, dk, dv from dO        (reference vision_transformer.py:63: the autograd of
 //   F.scaled_dot_product_attention inside Attention.forward, reached from train_video transformer_3d.py:79-100)
 // Flash-style: P is rebuilt from q, k and the forward's per-row log-sum-exp (attn_bf16 writes it in the log2 domain),
@@ -23,6 +23,8 @@ namespace nova {
 
 constexpr int B_T = 64;            // streamed rows per tile
 constexpr int B_IMG = B_T * 128;   // one 64 x 64 bf16 image, 8 KiB
+constexpr int B_IMG32 = B_T * 64;  // head_dim 96: the columns 64..95 as a second image with 64-byte rows, 4 KiB
+template <int HD> constexpr int tile_bytes() { return B_IMG + (HD == 96 ? B_IMG32 : 0); }
 constexpr float LN2 = 0.6931471805599453f;
 
 // Stage rows [t0, t0 + 64) of a token-major matrix (row stride rowB bytes, this head's 128-byte slice) into an LDS image
@@ -39,9 +41,21 @@ __device__ __forceinline__ void stage_tile(const char* base, uint32_t rowB, int 
   }
 }
 
-// row fragment (A operand, rows = tile rows): lane (r, hh) of block rb reads 8 bf16 at k = 16 ks + 8 hh
+// head_dim 96: the 32-wide image of the same rows (chunk c of row r at c ^ ((r >> 2) & 3), the forward's K32 image); wave w
+// moves piece w (16 rows x 64 B). `img` points at the 64-wide image, the 32-wide one follows it.
+template <int HD>
+__device__ __forceinline__ void stage_rows(const char* base, uint32_t rowB, int t0, int last, char* img, int wid, int lane) {
+  stage_tile(base, rowB, t0, last, img, wid, lane);
+  if constexpr (HD == 96) {
+    const int row = wid * 16 + (lane >> 2), scp = lane & 3;
+    glds16(base, (uint32_t)min(t0 + row, last) * rowB + 128u + (uint32_t)((scp ^ ((row >> 2) & 3)) << 4), img + B_IMG + wid * 1024);
+  }
+}
+
+// row fragment (A operand, rows = tile rows): lane (r, hh) of block rb reads 8 bf16 at k = 16 ks + 8 hh (ks >= 4: the 32-wide image)
 __device__ __forceinline__ bf8v frag_plain(const char* img, int row, int ks, int hh) {
-  return *reinterpret_cast<const bf8v*>(img + row * 128 + (((2 * ks + hh) ^ ((row >> 1) & 7)) << 4));
+  if (ks < 4) return *reinterpret_cast<const bf8v*>(img + row * 128 + (((2 * ks + hh) ^ ((row >> 1) & 7)) << 4));
+  return *reinterpret_cast<const bf8v*>(img + B_IMG + row * 64 + (((2 * (ks - 4) + hh) ^ ((row >> 2) & 3)) << 4));
 }
 
 // transposed fragment (A operand, rows = the 32 columns [32 cb, 32 cb + 32) of the tile, k = tile rows 16 j .. 16 j + 15 of
@@ -51,8 +65,14 @@ __device__ __forceinline__ bf8v frag_tr(const char* img, int cb, int rb, int j, 
   const int col = cb * 32 + 16 * t_gp + 4 * t_p;
   const int chunk = col >> 3, within = (t_p & 1) * 8;
   const int row0 = rb * 32 + 16 * j + 4 * hh + t_qr, row1 = row0 + 8;
-  const char* a0 = img + row0 * 128 + ((chunk ^ ((row0 >> 1) & 7)) << 4) + within;
-  const char* a1 = img + row1 * 128 + ((chunk ^ ((row1 >> 1) & 7)) << 4) + within;
+  const char *a0, *a1;
+  if (cb < 2) {
+    a0 = img + row0 * 128 + ((chunk ^ ((row0 >> 1) & 7)) << 4) + within;
+    a1 = img + row1 * 128 + ((chunk ^ ((row1 >> 1) & 7)) << 4) + within;
+  } else {  // columns 64..95: the 32-wide image
+    a0 = img + B_IMG + row0 * 64 + (((chunk - 8) ^ ((row0 >> 2) & 3)) << 4) + within;
+    a1 = img + B_IMG + row1 * 64 + (((chunk - 8) ^ ((row1 >> 2) & 3)) << 4) + within;
+  }
   const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
   const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a1);
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -79,12 +99,14 @@ __device__ __forceinline__ f16v zero16() {
 // ------------------------------------------------------------------------------------------
 // dq: workgroup = 128 query rows of one (sequence, head)
 // ------------------------------------------------------------------------------------------
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                       const bf16_t* __restrict__ v, const bf16_t* __restrict__ d_o,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       bf16_t* __restrict__ dq, int L, long qkv_rs, long do_rs, long dq_rs,
                                                       float scale, int heads, int nq) {
-  constexpr int BUF = 2 * B_IMG;  // [K | V]
+  constexpr int NKS = HD / 16, NDB = HD / 32, TILE = tile_bytes<HD>();
+  constexpr int BUF = 2 * TILE;  // [K | V]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,12 +118,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
   const int qrow = min(q0 + r, L - 1);
 
   // resident: Q~ and dO fragments of the lane's query (B operands), its lse and delta
-  bf8v qf[4], dof[4];
+  bf8v qf[NKS], dof[NKS];
   {
-    const bf16_t* qp = q + ((size_t)s * L + qrow) * qkv_rs + head * 64 + 8 * hh;
-    const bf16_t* dp = d_o + ((size_t)s * L + qrow) * do_rs + head * 64 + 8 * hh;
+    const bf16_t* qp = q + ((size_t)s * L + qrow) * qkv_rs + head * HD + 8 * hh;
+    const bf16_t* dp = d_o + ((size_t)s * L + qrow) * do_rs + head * HD + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       qf[ks] = *reinterpret_cast<const bf8v*>(qp + 16 * ks);
       dof[ks] = *reinterpret_cast<const bf8v*>(dp + 16 * ks);
     }
@@ -109,16 +131,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
   const float lse_q = lse[((size_t)s * heads + head) * L + qrow];
   const float del_q = delta[((size_t)s * heads + head) * L + qrow];
 
-  const char* kb_ = reinterpret_cast<const char*>(k + (size_t)s * L * qkv_rs + head * 64);
-  const char* vb_ = reinterpret_cast<const char*>(v + (size_t)s * L * qkv_rs + head * 64);
+  const char* kb_ = reinterpret_cast<const char*>(k + (size_t)s * L * qkv_rs + head * HD);
+  const char* vb_ = reinterpret_cast<const char*>(v + (size_t)s * L * qkv_rs + head * HD);
   const uint32_t rowB = (uint32_t)qkv_rs * 2u;
   auto stage = [&](int buf, int kt) {
     char* b = smem + buf * BUF;
-    stage_tile(kb_, rowB, kt * B_T, L - 1, b, wid, lane);
-    stage_tile(vb_, rowB, kt * B_T, L - 1, b + B_IMG, wid, lane);
+    stage_rows<HD>(kb_, rowB, kt * B_T, L - 1, b, wid, lane);
+    stage_rows<HD>(vb_, rowB, kt * B_T, L - 1, b + TILE, wid, lane);
   };
 
-  f16v dqt[2] = {zero16(), zero16()};  // dQ^T [d x q], two 32-row d blocks
+  f16v dqt[NDB];  // dQ^T [d x q] in 32-row d blocks
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) dqt[db] = zero16();
   const int nkt = (L + B_T - 1) / B_T;
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -126,14 +150,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
     __syncthreads();
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     const char* tk = smem + (kt & 1) * BUF;
-    const char* tv = tk + B_IMG;
+    const char* tv = tk + TILE;
     bf8v dsb[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int row = kb * 32 + r;
       f16v st = zero16(), dpt = zero16();
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < NKS; ++ks) {
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(tk, row, ks, hh), qf[ks], st, 0, 0, 0);    // S^T = K Q~^T
         dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(tv, row, ks, hh), dof[ks], dpt, 0, 0, 0); // dP^T = V dO^T
       }
@@ -146,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
       pack_acc(st, dsb[kb]);
     }
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -155,9 +179,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
   }
 
   if (q0 + r < L) {
-    bf16_t* op = dq + ((size_t)s * L + q0 + r) * dq_rs + head * 64;
+    bf16_t* op = dq + ((size_t)s * L + q0 + r) * dq_rs + head * HD;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * hh;
@@ -170,12 +194,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
 // ------------------------------------------------------------------------------------------
 // dk, dv: workgroup = 128 key rows of one (sequence, head)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+template <int HD>
+__global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                        const bf16_t* __restrict__ v, const bf16_t* __restrict__ d_o,
                                                        const float* __restrict__ lse, const float* __restrict__ delta,
                                                        bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int L, long qkv_rs,
                                                        long do_rs, long dkv_rs, int heads, int nk) {
-  constexpr int BUF = 2 * B_IMG + 2 * B_T * 4;  // [Q | dO | lse | delta]
+  constexpr int NKS = HD / 16, NDB = HD / 32, TILE = tile_bytes<HD>();
+  constexpr int BUF = 2 * TILE + 2 * B_T * 4;  // [Q | dO | lse | delta]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,33 +212,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
   const int k0 = kt0 * 128 + wid * 32;
   const int krow = min(k0 + r, L - 1);
 
-  bf8v kf[4], vf[4];  // B operands: the lane's key, 8 features at 16 ks + 8 hh
+  bf8v kf[NKS], vf[NKS];  // B operands: the lane's key, 8 features at 16 ks + 8 hh
   {
-    const bf16_t* kp = k + ((size_t)s * L + krow) * qkv_rs + head * 64 + 8 * hh;
-    const bf16_t* vp = v + ((size_t)s * L + krow) * qkv_rs + head * 64 + 8 * hh;
+    const bf16_t* kp = k + ((size_t)s * L + krow) * qkv_rs + head * HD + 8 * hh;
+    const bf16_t* vp = v + ((size_t)s * L + krow) * qkv_rs + head * HD + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < NKS; ++ks) {
       kf[ks] = *reinterpret_cast<const bf8v*>(kp + 16 * ks);
       vf[ks] = *reinterpret_cast<const bf8v*>(vp + 16 * ks);
     }
   }
-  const char* qb_ = reinterpret_cast<const char*>(q + (size_t)s * L * qkv_rs + head * 64);
-  const char* ob_ = reinterpret_cast<const char*>(d_o + (size_t)s * L * do_rs + head * 64);
+  const char* qb_ = reinterpret_cast<const char*>(q + (size_t)s * L * qkv_rs + head * HD);
+  const char* ob_ = reinterpret_cast<const char*>(d_o + (size_t)s * L * do_rs + head * HD);
   const float* lse_b = lse + ((size_t)s * heads + head) * L;
   const float* del_b = delta + ((size_t)s * heads + head) * L;
   const uint32_t qB = (uint32_t)qkv_rs * 2u, oB = (uint32_t)do_rs * 2u;
   auto stage = [&](int buf, int qt) {
     char* b = smem + buf * BUF;
-    stage_tile(qb_, qB, qt * B_T, L - 1, b, wid, lane);
-    stage_tile(ob_, oB, qt * B_T, L - 1, b + B_IMG, wid, lane);
+    stage_rows<HD>(qb_, qB, qt * B_T, L - 1, b, wid, lane);
+    stage_rows<HD>(ob_, oB, qt * B_T, L - 1, b + TILE, wid, lane);
     if (tid < 2 * B_T) {  // the tile's lse | delta (plain stores: visible after the barrier that opens the tile)
       const int i = tid & (B_T - 1);
       const int row = min(qt * B_T + i, L - 1);
-      reinterpret_cast<float*>(b + 2 * B_IMG)[tid] = tid < B_T ? lse_b[row] : del_b[row];
+      reinterpret_cast<float*>(b + 2 * TILE)[tid] = tid < B_T ? lse_b[row] : del_b[row];
     }
   };
 
-  f16v dkt[2] = {zero16(), zero16()}, dvt[2] = {zero16(), zero16()};  // dK^T, dV^T [d x key]
+  f16v dkt[NDB], dvt[NDB];  // dK^T, dV^T [d x key] in 32-row d blocks
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) dkt[db] = dvt[db] = zero16();
   const int nqt = (L + B_T - 1) / B_T;
   stage(0, 0);
   for (int qt = 0; qt < nqt; ++qt) {
@@ -220,15 +248,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
     __syncthreads();
     if (qt + 1 < nqt) stage((qt + 1) & 1, qt + 1);
     const char* tq = smem + (qt & 1) * BUF;
-    const char* to = tq + B_IMG;
-    const float* tl = reinterpret_cast<const float*>(tq + 2 * B_IMG);
+    const char* to = tq + TILE;
+    const float* tl = reinterpret_cast<const float*>(tq + 2 * TILE);
     bf8v pb[2][2], dsb[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int row = qb * 32 + r;
       f16v sa = zero16(), dpa = zero16();
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < NKS; ++ks) {
         sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(tq, row, ks, hh), kf[ks], sa, 0, 0, 0);    // S = Q~ K^T
         dpa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_plain(to, row, ks, hh), vf[ks], dpa, 0, 0, 0);  // dP = dO V^T
       }
@@ -247,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
       pack_acc(dpa, dsb[qb]);
     }
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -258,10 +286,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
   }
 
   if (k0 + r < L) {
-    bf16_t* kp = dk + ((size_t)s * L + k0 + r) * dkv_rs + head * 64;
-    bf16_t* vp = dv + ((size_t)s * L + k0 + r) * dkv_rs + head * 64;
+    bf16_t* kp = dk + ((size_t)s * L + k0 + r) * dkv_rs + head * HD;
+    bf16_t* vp = dv + ((size_t)s * L + k0 + r) * dkv_rs + head * HD;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = db * 32 + 8 * g + 4 * hh;
@@ -273,11 +301,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv(const bf16_t* __restrict_
   }
 }
 
-// delta[s, head, l] = sum_c dO[s, l, head, c] * O[s, l, head, c]: 8 lanes per (token, head), 16 bytes each
+// delta[s, head, l] = sum_c dO[s, l, head, c] * O[s, l, head, c]: 16 lanes per (token, head), 16 bytes each (HD / 8 of them active)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ o,
-                                                         float* __restrict__ delta, int L, int heads, long do_rs, long o_rs, long total) {
-  const long i = (long)blockIdx.x * 32 + (threadIdx.x >> 3);  // (s, l, head) index, head fastest
-  const int part = threadIdx.x & 7;
+                                                         float* __restrict__ delta, int L, int heads, int hd, long do_rs, long o_rs,
+                                                         long total) {
+  const long i = (long)blockIdx.x * 16 + (threadIdx.x >> 4);  // (s, l, head) index, head fastest
+  const int part = threadIdx.x & 15;
   float acc = 0.f;
   long s = 0;
   int l = 0, head = 0;
@@ -286,22 +315,27 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     const long sl = i / heads;
     l = (int)(sl % L);
     s = sl / L;
-    const u4v a = *reinterpret_cast<const u4v*>(d_o + sl * do_rs + head * 64 + part * 8);
-    const u4v b = *reinterpret_cast<const u4v*>(o + sl * o_rs + head * 64 + part * 8);
+    if (part * 8 < hd) {
+      const u4v a = *reinterpret_cast<const u4v*>(d_o + sl * do_rs + head * hd + part * 8);
+      const u4v b = *reinterpret_cast<const u4v*>(o + sl * o_rs + head * hd + part * 8);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      acc += __uint_as_float(a[j] << 16) * __uint_as_float(b[j] << 16) + __uint_as_float(a[j] & 0xffff0000u) * __uint_as_float(b[j] & 0xffff0000u);
+      for (int j = 0; j < 4; ++j)
+        acc += __uint_as_float(a[j] << 16) * __uint_as_float(b[j] << 16) + __uint_as_float(a[j] & 0xffff0000u) * __uint_as_float(b[j] & 0xffff0000u);
+    }
   }
   acc += dpp_move<0xb1>(acc);   // xor 1
   acc += dpp_move<0x4e>(acc);   // xor 2
-  acc += dpp_move<0x141>(acc);  // i <-> 7 - i: completes the 8-lane sum
+  acc += dpp_move<0x141>(acc);  // i <-> 7 - i
+  acc += dpp_move<0x140>(acc);  // i <-> 15 - i: completes the 16-lane sum
   if (i < total && part == 0) delta[(s * heads + head) * L + l] = acc;
 }
 
 int attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, void* dq,
-             void* dk, void* dv, int S, int heads, int L, long qkv_rs, long o_rs, long do_rs, long dqkv_rs, float scale, hipStream_t st) {
+             void* dk, void* dv, int S, int heads, int L, int hd, long qkv_rs, long o_rs, long do_rs, long dqkv_rs, float scale,
+             hipStream_t st) {
   if (S <= 0 || L <= 0) return 0;
   if (heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_bwd: bad heads");
+  if (hd != 64 && hd != 96) return set_error(NOVA_ERR_SHAPE, "attn_bwd: head_dim %d not built (have 64 and 96)", hd);
   if (qkv_rs % 8 || do_rs % 8 || dqkv_rs % 8 || o_rs % 8) return set_error(NOVA_ERR_SHAPE, "attn_bwd: row strides must be 16-byte multiples");
   if ((long)L * qkv_rs * 2 > 0x7fffffffL || (long)L * do_rs * 2 > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_bwd: a sequence's rows must span < 2 GiB");
   const int nt = (L + 127) / 128;
@@ -309,12 +343,18 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
   if (blocks > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_bwd: grid too large");
   const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v, *oo = (const bf16_t*)d_o;
   const long rows = (long)S * L * heads;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, oo, (const bf16_t*)o, delta, L, heads, do_rs,
-                     o_rs, rows);
-  hipLaunchKernelGGL(attn_bwd_dq, dim3((unsigned)blocks), dim3(256), 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dq, L, qkv_rs, do_rs,
-                     dqkv_rs, scale, heads, nt);
-  hipLaunchKernelGGL(attn_bwd_dkv, dim3((unsigned)blocks), dim3(256), 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dk, (bf16_t*)dv, L,
-                     qkv_rs, do_rs, dqkv_rs, heads, nt);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, oo, (const bf16_t*)o, delta, L, heads, hd,
+                     do_rs, o_rs, rows);
+  const dim3 grid((unsigned)blocks), block(256);
+  if (hd == 64) {
+    hipLaunchKernelGGL(attn_bwd_dq<64>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dq, L, qkv_rs, do_rs, dqkv_rs, scale, heads, nt);
+    hipLaunchKernelGGL(attn_bwd_dkv<64>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dk, (bf16_t*)dv, L, qkv_rs, do_rs, dqkv_rs,
+                       heads, nt);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq<96>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dq, L, qkv_rs, do_rs, dqkv_rs, scale, heads, nt);
+    hipLaunchKernelGGL(attn_bwd_dkv<96>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dk, (bf16_t*)dv, L, qkv_rs, do_rs, dqkv_rs,
+                       heads, nt);
+  }
   return check_launch("attn_bwd");
 }
 

@@ -187,18 +187,18 @@ int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, i
 }
 
 int nova_attn_fwd_lse(const void* q_scaled, const void* k, const void* v, void* o, float* lse, int S, int heads, int L,
-                      long qkv_row_stride, long o_row_stride, void* stream) {
+                      int head_dim, long qkv_row_stride, long o_row_stride, void* stream) {
   NOVA_REQUIRE(q_scaled && k && v && o && lse, NOVA_ERR_ARG, "attn_fwd_lse: null pointer");
-  return attn_fwd(q_scaled, k, v, o, S, heads, L, L, 64, qkv_row_stride, qkv_row_stride, o_row_stride, 1.0f, NOVA_BF16,
+  return attn_fwd(q_scaled, k, v, o, S, heads, L, L, head_dim, qkv_row_stride, qkv_row_stride, o_row_stride, 1.0f, NOVA_BF16,
                   (hipStream_t)stream, true, 0, lse);
 }
 
 int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
-                  float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, long qkv_row_stride,
-                  long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream) {
+                  float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, int head_dim,
+                  long qkv_row_stride, long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream) {
   NOVA_REQUIRE(q_scaled && k && v && o && d_o && lse && delta_scratch && dq && dk && dv, NOVA_ERR_ARG, "attn_bwd: null pointer");
-  return attn_bwd(q_scaled, k, v, o, d_o, lse, delta_scratch, dq, dk, dv, S, heads, L, qkv_row_stride, o_row_stride, do_row_stride,
-                  dqkv_row_stride, scale, (hipStream_t)stream);
+  return attn_bwd(q_scaled, k, v, o, d_o, lse, delta_scratch, dq, dk, dv, S, heads, L, head_dim, qkv_row_stride, o_row_stride,
+                  do_row_stride, dqkv_row_stride, scale, (hipStream_t)stream);
 }
 
 int nova_row_norm(const void* in, void* out, const float* gamma, const float* beta, const void* mod, long mod_ld,

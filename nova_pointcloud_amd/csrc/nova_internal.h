@@ -42,11 +42,12 @@ bool walk_is_reverse();
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
              long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st,
              bool q_prescaled = false, long kv_seq_stride = 0, float* lse = nullptr);
-// attn_bwd.hip (bf16, head_dim 64): gradients of the attention above from q (pre-scaled by scale * log2 e), k, v, the
+// attn_bwd.hip (bf16, head_dim 64 / 96): gradients of the attention above from q (pre-scaled by scale * log2 e), k, v, the
 // forward's output o and log2-domain row log-sum-exp, and dO; delta [S, heads, L] is scratch (filled with sum_c dO * O first).
-// All matrices token-major [S, L, heads * 64] with row strides.
+// All matrices token-major [S, L, heads * hd] with row strides.
 int attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, void* dq,
-             void* dk, void* dv, int S, int heads, int L, long qkv_rs, long o_rs, long do_rs, long dqkv_rs, float scale, hipStream_t st);
+             void* dk, void* dv, int S, int heads, int L, int hd, long qkv_rs, long o_rs, long do_rs, long dqkv_rs, float scale,
+             hipStream_t st);
 
 // ---- rowops.hip
 struct RowNormArgs {

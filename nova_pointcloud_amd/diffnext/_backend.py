@@ -37,5 +37,5 @@ def autograd():
 
 
 def train_attention_supported(q, attn_mask):
-    """bf16 device tensors [S, heads, L, 64] without a mask: the case the HIP attention backward is built for."""
+    """bf16 device tensors [S, heads, L, 64 | 96] without a mask: the case the HIP attention backward is built for."""
     return q.is_cuda and autograd().attention_supported(q, attn_mask)

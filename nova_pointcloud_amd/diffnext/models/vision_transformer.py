@@ -8,7 +8,7 @@ Execution. With device tensors and autograd off, whole block stacks run on libno
 (`nova_vit_blocks_forward`: fused QKV + RoPE GEMM, flash attention reading q / k / v in place, GEMM + GELU, fused
 LayerNorm + residual) and raise if the library is missing; the generation loop bypasses even this and drives the
 stacks from nova_pointcloud_amd/engine.py. With CPU tensors or autograd on (training) the PyTorch definition runs, with
-the attention itself (forward and backward) on the HIP kernels for bf16 device tensors of head_dim 64.
+the attention itself (forward and backward) on the HIP kernels for bf16 device tensors of head_dim 64 / 96.
 """
 from typing import Tuple
 

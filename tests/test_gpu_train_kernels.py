@@ -30,18 +30,19 @@ def _rel(got, ref):
 
 @pytest.mark.parametrize("S,h,L", [(1, 1, 64), (2, 3, 128), (1, 2, 200), (2, 1, 333), (1, 4, 1031), (3, 2, 31)])
 @pytest.mark.parametrize("spread", [1.0, 4.0])
-def test_attention_forward_backward_match_autograd(hip, S, h, L, spread):
+@pytest.mark.parametrize("hd", [64, 96])
+def test_attention_forward_backward_match_autograd(hip, S, h, L, spread, hd):
     from nova_pointcloud_amd import autograd as A
 
-    g = torch.Generator().manual_seed(S * 1000 + h * 100 + L)
-    mk = lambda s: (torch.randn(S, h, L, 64, generator=g) * s).bfloat16().cuda()
+    g = torch.Generator().manual_seed(S * 1000 + h * 100 + L + hd)
+    mk = lambda s: (torch.randn(S, h, L, hd, generator=g) * s).bfloat16().cuda()
     q, k, v, d_out = mk(spread), mk(1.0), mk(1.0), mk(1.0)  # spread > 1: peaked rows (large score range)
     q, k, v = (t.requires_grad_(True) for t in (q, k, v))
     assert A.attention_supported(q)
     out = A.attention(q, k, v)
     out.backward(d_out)
     o_ref, dq_ref, dk_ref, dv_ref = _ref(q, k, v, d_out)
-    assert out.shape == (S, h, L, 64) and q.grad.shape == q.shape
+    assert out.shape == (S, h, L, hd) and q.grad.shape == q.shape
     assert _rel(out, o_ref) < 1.6e-2
     for name, got, ref in (("dq", q.grad, dq_ref), ("dk", k.grad, dk_ref), ("dv", v.grad, dv_ref)):
         assert torch.isfinite(got.float()).all(), name
