@@ -271,3 +271,37 @@ def test_training_step_matches_reference(gold):
         assert (got - want).abs().max() <= 2e-5 * want.abs().max() + 1e-9
         checked += 1
     assert checked >= 5
+
+
+def test_training_attention_dispatch_rules():
+    """Host logic of the training hook (nova_pointcloud_amd/autograd.py): only bf16 device tensors [S, heads, L, 64 | 96]
+    without a mask go to the HIP attention; everything else keeps F.scaled_dot_product_attention. On this CPU-only side
+    nothing may qualify, and `Attention.forward` with grad enabled must run (and differentiate) without the library."""
+    from diffnext.models.vision_transformer import Attention
+    from nova_pointcloud_amd import autograd as A
+
+    q = torch.zeros(2, 3, 16, 64, dtype=torch.bfloat16)
+    assert not A.attention_supported(q)                                   # CPU tensor
+    meta = torch.zeros(2, 3, 16, 64, dtype=torch.bfloat16, device="meta")
+    assert not A.attention_supported(meta)                                # not a CUDA device
+    before = A.stats["attention_calls"]
+    attn = Attention(128, 2)
+    x = torch.randn(2, 10, 128, requires_grad=True)
+    attn(x).square().mean().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and A.stats["attention_calls"] == before
+
+    class FakeCuda(object):  # shape / dtype / mask gating without a device
+        is_cuda = True
+
+        def __init__(self, shape, dtype):
+            self.shape, self.dtype = shape, dtype
+
+        def dim(self):
+            return len(self.shape)
+
+    ok = FakeCuda((2, 3, 16, 64), torch.bfloat16)
+    assert A.attention_supported(ok) == A._ENABLED and A.attention_supported(FakeCuda((2, 3, 16, 96), torch.bfloat16)) == A._ENABLED
+    assert not A.attention_supported(ok, attn_mask=torch.zeros(16, 16))
+    assert not A.attention_supported(FakeCuda((2, 3, 16, 64), torch.float32))
+    assert not A.attention_supported(FakeCuda((2, 3, 16, 128), torch.bfloat16))
+    assert not A.attention_supported(FakeCuda((6, 16, 64), torch.bfloat16))
