@@ -27,17 +27,24 @@ constexpr int B_IMG32 = B_T * 64;  // head_dim 96: the columns 64..95 as a secon
 template <int HD> constexpr int tile_bytes() { return B_IMG + (HD == 96 ? B_IMG32 : 0); }
 constexpr float LN2 = 0.6931471805599453f;
 
-// Stage rows [t0, t0 + 64) of a token-major matrix (row stride rowB bytes, this head's 128-byte slice) into an LDS image
-// with chunk c of row r at c ^ ((r >> 1) & 7): conflict-free ds_read_b128 of row fragments, and the transposing
-// ds_read_b64_tr_b16 reads of the same image run as fast as from an image of their own (measured: staging every tile a
-// second time in the forward's V-image swizzle was 1-3 % slower). Wave w moves pieces 2w, 2w+1 (8 rows each). Rows past
-// `last` re-read row `last` (callers mask them).
+// LDS image of a streamed 64 x 64 tile: chunk c (16 bytes) of row r sits at chunk c ^ swz(r), swz = the three bits of r >> 1
+// in REVERSED order. Two read kinds hit this image and both must be conflict-free:
+//   ds_read_b128 of row fragments: 16 consecutive rows x one chunk per pass - swz takes all 8 values over the 8 row pairs
+//     (any bijection of (r >> 1) & 7 does that; rows 2j and 2j + 1 are 32 banks apart by themselves);
+//   ds_read_b64_tr_b16 of transposed fragments: rows r .. r + 3 (r % 4 == 0) x 64 contiguous bytes per pass - rows r and
+//     r + 2 must land 64 bytes apart, i.e. swz(r) ^ swz(r + 2) = 4: the LOW bit of r >> 1 has to become bit 2. With the
+//     forward's K swizzle ((r >> 1) & 7 unreversed) those reads lost 25 % of the LDS-active cycles to bank conflicts
+//     (SQ_LDS_BANK_CONFLICT); staging a second image in the forward's V swizzle cost more than it saved.
+__device__ __forceinline__ int swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 1) & 2) | ((row >> 3) & 1); }
+
+// Stage rows [t0, t0 + 64) of a token-major matrix (row stride rowB bytes, this head's first 128 bytes) into that image.
+// Wave w moves pieces 2w, 2w+1 (8 rows each). Rows past `last` re-read row `last` (callers mask them).
 __device__ __forceinline__ void stage_tile(const char* base, uint32_t rowB, int t0, int last, char* img, int wid, int lane) {
   const int scp = lane & 7;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (wid * 2 + i) * 8 + (lane >> 3);
-    glds16(base, (uint32_t)min(t0 + row, last) * rowB + (uint32_t)((scp ^ ((row >> 1) & 7)) << 4), img + (wid * 2 + i) * 1024);
+    glds16(base, (uint32_t)min(t0 + row, last) * rowB + (uint32_t)((scp ^ swz(row)) << 4), img + (wid * 2 + i) * 1024);
   }
 }
 
@@ -54,7 +61,7 @@ __device__ __forceinline__ void stage_rows(const char* base, uint32_t rowB, int 
 
 // row fragment (A operand, rows = tile rows): lane (r, hh) of block rb reads 8 bf16 at k = 16 ks + 8 hh (ks >= 4: the 32-wide image)
 __device__ __forceinline__ bf8v frag_plain(const char* img, int row, int ks, int hh) {
-  if (ks < 4) return *reinterpret_cast<const bf8v*>(img + row * 128 + (((2 * ks + hh) ^ ((row >> 1) & 7)) << 4));
+  if (ks < 4) return *reinterpret_cast<const bf8v*>(img + row * 128 + (((2 * ks + hh) ^ swz(row)) << 4));
   return *reinterpret_cast<const bf8v*>(img + B_IMG + row * 64 + (((2 * (ks - 4) + hh) ^ ((row >> 2) & 3)) << 4));
 }
 
@@ -67,8 +74,8 @@ __device__ __forceinline__ bf8v frag_tr(const char* img, int cb, int rb, int j, 
   const int row0 = rb * 32 + 16 * j + 4 * hh + t_qr, row1 = row0 + 8;
   const char *a0, *a1;
   if (cb < 2) {
-    a0 = img + row0 * 128 + ((chunk ^ ((row0 >> 1) & 7)) << 4) + within;
-    a1 = img + row1 * 128 + ((chunk ^ ((row1 >> 1) & 7)) << 4) + within;
+    a0 = img + row0 * 128 + ((chunk ^ swz(row0)) << 4) + within;
+    a1 = img + row1 * 128 + ((chunk ^ swz(row1)) << 4) + within;
   } else {  // columns 64..95: the 32-wide image
     a0 = img + B_IMG + row0 * 64 + (((chunk - 8) ^ ((row0 >> 2) & 3)) << 4) + within;
     a1 = img + B_IMG + row1 * 64 + (((chunk - 8) ^ ((row1 >> 2) & 3)) << 4) + within;
