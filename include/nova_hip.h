@@ -61,6 +61,11 @@ int nova_prof_collect(double* ms, double* work, long long* launches, int slots);
  * bit-identical results (tests/test_gpu_kernels.py compares them). Per calling thread. */
 int nova_debug_force_gemm_tile(int tile);
 
+/* Test / A-B hook: which structure the bf16, head_dim 64 attention launches for the calling thread: 0 = 32x32x16 MFMA,
+ * 32 query rows per wave; 1 = 16x16x32 MFMA, 32 rows per wave; 2 = 16x16x32 MFMA, 64 rows per wave; 3 / 4 = 1 / 2 with the softmax row sums taken on the matrix pipe (an
+ * all-ones V^T block) instead of vector adds; -1 = the shipped default. Same algorithm in all three (tests/test_gpu_kernels.py compares each with the f32 reference and with each other). */
+int nova_debug_set_attn_variant(int variant);
+
 /* nova_decoder_denoise replays its launch sequence as a hipGraph, captured once per distinct argument set (on by
  * default; environment NOVA_GRAPHS=0 or on = 0 here switches to direct launches and drops the cached graphs of the
  * calling thread). Results are identical either way. Stats: graphs captured / replayed by the calling thread. */

@@ -382,6 +382,16 @@ __global__ __launch_bounds__(256) void attn_f32(const float* __restrict__ q, con
   }
 }
 
+// which bf16 / head_dim 64 structure nova_attn_fwd launches (per calling thread): 0 = 32x32x16 (attn_bf16 above),
+// 1 / 2 = 16x16x32 with 32 / 64 query rows per wave (attn16.hip), 3 / 4 = the same with the row sums on the matrix pipe, 5 = 4 software-pipelined (P V of tile t-1 beside the exponentials of tile t); -1 = the shipped choice
+static thread_local int g_attn_variant = -1;
+int attn_set_variant(int v) {
+  if (v < -1 || v > 5) return -1;
+  g_attn_variant = v;
+  return 0;
+}
+int attn_variant() { return g_attn_variant < 0 ? NOVA_ATTN_DEFAULT_VARIANT : g_attn_variant; }
+
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
              long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st, bool q_prescaled, long kv_ss, float* lse) {
   if (S <= 0 || Lq <= 0) return 0;
@@ -401,6 +411,8 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
     const float cl = q_prescaled ? 1.0f : c;
     const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v;
     const int rev = walk_is_reverse() ? 1 : 0;
+    if (hd == 64 && attn_variant() != 0)
+      return attn_fwd_m16(qq, kk, vv, (bf16_t*)o, S, heads, Lq, Lk, q_rs, kv_rs, o_rs, cl, st, kv_ss, lse, (attn_variant() & 1) && attn_variant() != 5 ? 32 : 64, attn_variant() >= 3, attn_variant() == 5);
     if (lse && hd == 64) hipLaunchKernelGGL((attn_bf16<64, true>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
     else if (lse) hipLaunchKernelGGL((attn_bf16<96, true>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
     else if (hd == 64) hipLaunchKernelGGL((attn_bf16<64, false>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);

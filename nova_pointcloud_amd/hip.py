@@ -100,6 +100,7 @@ SIGNATURES = {
 SIGNATURES["nova_prof_enable"] = [c_int]
 SIGNATURES["nova_debug_force_gemm_tile"] = [c_int]
 SIGNATURES["nova_debug_set_graphs"] = [c_int]
+SIGNATURES["nova_debug_set_attn_variant"] = [c_int]
 SIGNATURES["nova_debug_graph_stats"] = [ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
 SIGNATURES["nova_prof_collect"] = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_longlong), c_int]

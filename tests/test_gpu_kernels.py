@@ -169,6 +169,31 @@ def test_attention_spiky_rows(hip, dtype, hd):
     assert relerr(out, ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("S,heads,L", [(1, 1, 64), (2, 3, 200), (1, 2, 333), (3, 1, 31), (1, 4, 769), (2, 2, 2560)])
+def test_attention_structures_bf16(hip, variant, S, heads, L):
+    """The three bf16 / head_dim 64 structures (32x32x16; 16x16x32 at 32 and at 64 query rows per wave) against SDPA in f32,
+    incl. ragged last tiles and the forced late-max rescale (cdna_hip_programming rule 26)."""
+    hd, dtype = 64, torch.bfloat16
+    D = heads * hd
+    qkv = rnd(S * L, 3 * D, dtype=dtype, seed=7)
+    if L >= 200:  # spike: key L-3 aligned with query 5, key 70 with query 77 of head 0 -> the running max jumps late in the stream
+        q = qkv[:, :hd].float()
+        qkv[L - 3, D:D + hd] = (q[5] * 4).to(dtype)
+        qkv[70, D:D + hd] = (q[77] * 3).to(dtype)
+    q, k, v = qkv.float().view(S, L, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S * L, D)
+    try:
+        hip.call("nova_debug_set_attn_variant", variant)
+        out = hip.attn_fwd_packed(qkv, S, L, heads)
+    finally:
+        hip.call("nova_debug_set_attn_variant", -1)
+    assert relerr(out, ref) < tol(dtype)
+    # row-wise: every query row within bf16 rounding of the reference row (a wrong lane map hides in a global norm)
+    row_err = (out.float() - ref).abs().amax(1) / ref.abs().amax(1).clamp_min(1e-6)
+    assert row_err.max().item() < 4e-2, (variant, row_err.argmax().item(), row_err.max().item())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("D", [128, 768, 1024, 1536])
 def test_row_norm_variants(hip, dtype, D):
