@@ -86,10 +86,11 @@ def host_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(pipe, width, heads, H, W, threads):
-    """Oracle (port of the reference CPU path) on a bounded sample of the SAME architecture: B=1, the first two set
-    sizes of a 2-step cosine schedule over all N points, 2 diffusion steps; converted to points/s of the full
-    workload by the FLOP ratio."""
+def cpu_baseline(pipe, width, heads, H, W, threads, with_config0=False):
+    """Oracle (port of the reference CPU path) on a bounded sample of the SAME architecture, as BASELINE.md section 4 plans it:
+    B=1, all N points, 4 AR x 4 diffusion steps (2 x 2 above width 1024, to stay near 20 s of CPU work), converted to points/s
+    of the full 64 x 25 workload by the FLOP ratio. `with_config0`: BASELINE configs[0] (d48w768, 256 points, 4 x 4, batch 1,
+    the reference's own CPU-runnable case) timed IN FULL as well, reported under "config0"."""
     from oracle import nova_oracle as O
 
     torch.set_num_threads(threads)
@@ -98,17 +99,33 @@ def cpu_baseline(pipe, width, heads, H, W, threads):
     cfg = O.make_config(3, (H, W), 1, width, heads, 16, 32, 6, 256, rotary=True)
     g = torch.Generator().manual_seed(5)
     prompt = O.encode_prompt_embeds(sd["text_embed.weight"], [0.02 * torch.randn(24, 2560, generator=g)], 256)
-    sched, S = O.cosine_schedule(N, 2), 2
+    K = S = 4 if width <= 1024 else 2
+    sched = [int(v) for v in O.cosine_schedule(N, K) if v > 0]
     t0 = time.time()
     with torch.no_grad():
         O.generate(sd, cfg, prompt, sched, num_diffusion_steps=S, guidance_scale=5.0, generator=g)
     dt = time.time() - t0
-    sample_flops = flops_per_sample(width, N, Nv, 256, [int(v) for v in sched], S)
+    sample_flops = flops_per_sample(width, N, Nv, 256, sched, S)
     full = flops_per_sample(width, N, Nv, 256, [int(v) for v in O.cosine_schedule(N, 64) if v > 0], 25)
     tflops = sample_flops / dt / 1e12
-    return {"value": round(tflops * 1e12 / (full / N), 3), "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32, same d48w{width} weights, B=1, {N} points, 2 AR x 2 diffusion steps "
-                      f"({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {tflops:.3f} TFLOP/s), scaled by FLOPs to 64x25"}
+    rec = {"value": round(tflops * 1e12 / (full / N), 3), "unit": "points/s", "cores": threads, "kind": "port",
+           "sample": f"oracle fp32, same d48w{width} weights, B=1, {N} points, {K} AR x {S} diffusion steps "
+                     f"({sample_flops / 1e12:.2f} TFLOP in {dt:.1f} s = {tflops:.3f} TFLOP/s), scaled by FLOPs to 64x25"}
+    if with_config0:
+        del sd
+        p0 = build_pipeline(768, 12, 16, 16, torch.float32, torch.device("cpu"))
+        sd0 = {k: v.detach().float() for k, v in p0.transformer.state_dict().items()}
+        cfg0 = O.make_config(3, (16, 16), 1, 768, 12, 16, 32, 6, 256, rotary=True)
+        prompt0 = O.encode_prompt_embeds(sd0["text_embed.weight"], [0.02 * torch.randn(24, 2560, generator=g)], 256)
+        sched0 = [int(v) for v in O.cosine_schedule(256, 4) if v > 0]
+        t0 = time.time()
+        with torch.no_grad():
+            O.generate(sd0, cfg0, prompt0, sched0, num_diffusion_steps=4, guidance_scale=5.0, generator=g)
+        dt0 = time.time() - t0
+        f0 = flops_per_sample(768, 256, 64, 256, sched0, 4)
+        rec["config0"] = {"workload": "d48w768, 256 points, 4 AR x 4 diffusion steps, batch 1, in full (BASELINE configs[0])",
+                          "seconds": round(dt0, 2), "points_per_s": round(256 / dt0, 1), "tflops": round(f0 / dt0 / 1e12, 3)}
+    return rec
 
 
 PMC_KERNEL = {"attention": "attn_bf16<64,false>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
@@ -152,8 +169,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch override (0 = workload default)")
     ap.add_argument("--ar-steps", type=int, default=64)
     ap.add_argument("--diffusion-steps", type=int, default=25)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "fp8"],
                     help="fp8: bf16 model with the encoder's QKV / fc1 / fc2 GEMMs on the block-scaled fp8 MFMA (configs[4]; never the headline)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total samples over all ranks (0 = gpus x per-GPU batch); a value that does not divide gives ragged shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dry-run", action="store_true",
                     help="rehearse the multi-process control flow on CPU (gloo, PyTorch module path, f32): not a measurement")
@@ -189,12 +208,13 @@ def main():
 
     width, heads, H, W, B = WORKLOADS[args.workload]
     B = args.batch or B
-    dtype = torch.float32 if (dry or args.dtype == "f32") else torch.bfloat16
+    dtype = torch.float32 if (dry or args.dtype == "f32") else torch.float16 if args.dtype == "f16" else torch.bfloat16
     call_extra = {"gemm_dtype": "fp8"} if args.dtype == "fp8" else {}
     pipe = build_pipeline(width, heads, H, W, dtype, device)
     # the GLOBAL batch of prompts and ONE seed on every rank: each rank generates its contiguous block of samples and draws
     # the order / noise tensors of the global batch (sharding.py: sharded(seed) == unsharded(seed))
-    prompts = synthetic_prompts(world * B, device, dtype, seed=1234)
+    G = args.global_batch or world * B  # global batch
+    prompts = synthetic_prompts(G, device, dtype, seed=1234)
     gen = torch.Generator(device=device).manual_seed(0)
     sync = (lambda: None) if dry else torch.cuda.synchronize
     N, Nv = H * W, (H // 2) * (W // 2)
@@ -202,6 +222,8 @@ def main():
     def step(**extra):
         # per-rank pipeline call on its shard + the path's only exchange: all_gather of the generated point sets
         # (RCCL over xGMI; no collective at N = 1)
+        if dry:
+            gen.manual_seed(0)  # rehearsal: every step regenerates the same batch, so rank 0 can check it against an unsharded run
         return generate_sharded(pipe, prompts, rank, world, num_inference_steps=args.ar_steps,
                                 num_diffusion_steps=args.diffusion_steps, guidance_scale=5, generator=gen, **call_extra, **extra)
 
@@ -237,23 +259,46 @@ def main():
         prof = hip.prof_collect()
         hip.prof_enable(False)
     assert torch.isfinite(pts).all(), "non-finite points generated"
-    assert pts.shape[0] == world * B, "gathered point sets do not cover the global batch"
+    assert pts.shape[0] == G, "gathered point sets do not cover the global batch"
+    from nova_pointcloud_amd.sharding import shard_range
+
+    ranks_seen, shards = [0], [[0, 0, G]]
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+        # what the process group itself reports: every rank contributes its own rank id through the collective, so the
+        # JSON line proves how many ranks RCCL (gloo in the dry run) actually connected
+        ids = torch.empty(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(ids, torch.tensor([rank], dtype=torch.int64, device=device))
+        ranks_seen = sorted(int(v) for v in ids.tolist())
+        assert ranks_seen == list(range(dist.get_world_size())), ranks_seen
+        # per-rank prompt order: [rank, lo, hi) of the global prompt list each rank generated, as the ranks report it
+        mine = torch.tensor([rank, *shard_range(G, rank, world)], dtype=torch.int64, device=device)
+        allr = torch.empty(world * 3, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allr, mine)
+        shards = allr.view(world, 3).tolist()
 
     if rank == 0:
         schedule = [int(v) for v in cosine_set_sizes(N, args.ar_steps) if v > 0]
         fl = flops_per_sample(width, N, Nv, 256, schedule, args.diffusion_steps)
-        value = world * B * N * args.steps / elapsed
+        value = G * N * args.steps / elapsed
         e2e_tflops = value / N * fl / 1e12 / world  # per GPU
         fams = {k: {"ms": round(ms, 2), "launches": n,
                     "rate": round(wk / ms / (1e6 if k == "row_norm" else 1e9), 2) if ms > 0 else 0.0,  # GB/s | TFLOP/s
                     "unit": "GB/s" if k == "row_norm" else "TFLOP/s"} for k, (ms, wk, n) in prof.items() if n}
         mfma = {k: v for k, v in fams.items() if k != "row_norm"}
         if dry:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "points": list(pts.shape), "ms_per_step": round(elapsed / args.steps * 1e3, 2)}), flush=True)
+            # rehearsal only: rank 0 also generates the whole batch unsharded from the same seed - the gathered rows must
+            # be the same samples in the same (prompt) order
+            from diffnext.pipelines.nova.pipeline_nova import points_from_latents
+
+            whole = points_from_latents(pipe(prompt_embeds=prompts, output_type="latent", disable_progress_bar=True,
+                                             num_inference_steps=args.ar_steps, num_diffusion_steps=args.diffusion_steps, guidance_scale=5,
+                                             generator=torch.Generator(device=device).manual_seed(0)).frames).float()
+            diff = float((whole - pts.float()).abs().max() / whole.abs().max())
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": ranks_seen, "shards": shards, "points": list(pts.shape),
+                              "sharded_vs_unsharded_max_rel_diff": diff, "ms_per_step": round(elapsed / args.steps * 1e3, 2)}), flush=True)
             if distributed:
                 dist.barrier()
                 dist.destroy_process_group()
@@ -274,8 +319,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8 (QKV / fc1 / fc2 GEMMs) + bf16" if args.dtype == "fp8" else args.dtype, "data": "synthetic",
             "config": {"workload": args.workload, "points_per_sample": N, "ar_steps": len(schedule),
-                       "diffusion_steps": args.diffusion_steps, "batch_per_gpu": B, "global_batch": world * B,
-                       "guidance": "cfg 2-pass", "sharding": f"batch rows over {world} GPU(s), all_gather of points"},
+                       "diffusion_steps": args.diffusion_steps, "batch_per_gpu": B, "global_batch": G, "shards": shards,
+                       "guidance": "cfg 2-pass", "sharding": f"batch rows over {world} GPU(s), all_gather of points",
+                       "ranks_seen": ranks_seen, "process_group": (dist.get_backend() if distributed else "none")},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["rate"], "peak": peak,
                          "unit": "TFLOP/s", "frac": round(mfma[dom]["rate"] / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "avg_launch_ms": round(mfma[dom]["ms"] / mfma[dom]["launches"], 4),
@@ -288,7 +334,7 @@ def main():
             "kernels": fams,
         }
         if world == 1 and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(pipe, width, heads, H, W, threads=host_cores())
+            rec["cpu_baseline"] = cpu_baseline(pipe, width, heads, H, W, threads=host_cores(), with_config0=args.workload.startswith("d48w1024"))
         print(json.dumps(rec), flush=True)
     if distributed:
         dist.barrier()

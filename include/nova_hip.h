@@ -16,7 +16,9 @@
  *   - every function returns 0 on success or a negative nova_status; nova_last_error() returns a
  *     thread-local message for the last failure. Nothing throws.
  *   - dtype: storage type of activations and GEMM weights (NOVA_F32 = parity mode on exact-f32
- *     MFMA, NOVA_BF16 = throughput mode on bf16 MFMA). Biases, LayerNorm affine parameters, RoPE
+ *     MFMA, NOVA_BF16 / NOVA_F16 = throughput mode on the bf16 / f16 MFMA forms - same kernels, same rate; f16 is the
+ *     default precision of the reference's callers, scripts/app_nova_t2i.py:36,87-89. The fp8 GEMM mode and the training
+ *     (backward) entries take bf16 only). Biases, LayerNorm affine parameters, RoPE
  *     tables, point coordinates, timesteps and sigmas are always float32; token ids are int64
  *     (torch.long, as the reference's pred_ids / prev_ids).
  *   - row-major everywhere; a "row" is one token's feature vector.
@@ -28,9 +30,9 @@
 extern "C" {
 #endif
 
-#define NOVA_HIP_VERSION 202 /* 0.2.2: nova_attn_fwd_lse, nova_attn_bwd; 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
+#define NOVA_HIP_VERSION 300 /* 0.3.0: NOVA_F16 storage mode through every dtype-taking entry, nova_row_norm_chain takes a dtype, nova_debug_set_attn_variant; 0.2.2: nova_attn_fwd_lse, nova_attn_bwd; 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
 
-typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1 } nova_dtype;
+typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1, NOVA_F16 = 2 } nova_dtype;
 typedef enum { NOVA_ACT_NONE = 0, NOVA_ACT_GELU_ERF = 1, NOVA_ACT_SILU = 2 } nova_act;
 typedef enum {
   NOVA_OK = 0,
@@ -154,7 +156,7 @@ int nova_row_norm(const void* in, void* out, const float* gamma, const float* be
  * result equals nova_row_norm twice, bit for bit. x_new_out may be NULL (x not needed afterwards: the last block). */
 int nova_row_norm_chain(const void* g, const void* x, const float* gamma, const float* beta, const void* mod, long mod_ld,
                         int gate_off, int scale_off, int shift_off, float eps_first, float eps_second, void* x_new_out,
-                        void* h_out, long rows, int D, void* stream);
+                        void* h_out, long rows, int D, int dtype, void* stream);
 
 /* out = act(h W^T + bias) with h = LN(x)(1 + mod[:, scale_off:+D]) + mod[:, shift_off:+D], LN without affine: the first
  * half of DiffusionBlock.forward, `self.proj(self.norm1(x, z)...)` up to the activation (diffusion_mlp.py:41-47 with

@@ -35,9 +35,9 @@ constexpr int A_T32 = A_KV * 64;         // 32-wide image (HD = 96 only): 64-byt
 // applied at load (c != 1) for generic callers - and the running max is carried as the C operand of the first
 // QK^T MFMA (a 16-register block holding -m), so the softmax needs no multiply-subtract per score: p = exp2(acc).
 // The block is rewritten only when the deferred-rescale branch fires.
-template <int HD, bool LSE>  // LSE: the training forward, which also writes the row log-sum-exp (attn_bwd.hip)
-__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                                    const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+template <typename E, int HD, bool LSE>  // E: bf16_t / f16_t; LSE: the training forward, which also writes the row log-sum-exp (attn_bwd.hip)
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const E* __restrict__ q, const E* __restrict__ k,
+                                                                    const E* __restrict__ v, E* __restrict__ o,
                                                                     int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
                                                                     int heads, int nq, int rev, long kv_ss, float* __restrict__ lse) {
   constexpr int NKS = HD / 16, NDV = HD / 32;
@@ -53,22 +53,25 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
   const int head = sh % heads, s = sh / heads;
   const int q0 = qt * 128 + wid * 32;
 
-  const bf16_t* qb = q + (size_t)s * Lq * q_rs + head * HD;
-  const bf16_t* kb_ = k + (size_t)s * kv_ss + head * HD;
-  const bf16_t* vb_ = v + (size_t)s * kv_ss + head * HD;
+  const E* qb = q + (size_t)s * Lq * q_rs + head * HD;
+  const E* kb_ = k + (size_t)s * kv_ss + head * HD;
+  const E* vb_ = v + (size_t)s * kv_ss + head * HD;
 
   // Q fragments: B operand of S^T = K Q^T; lane (r, hh) holds Q[q0 + r][16 ks + 8 hh + 0..7]
-  bf8v qf[NKS];
+  u4v qf[NKS];
   {
     const int qrow = min(q0 + r, Lq - 1);
-    const bf16_t* qp = qb + (size_t)qrow * q_rs + 8 * hh;
+    const E* qp = qb + (size_t)qrow * q_rs + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf8v*>(qp + 16 * ks);
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const u4v*>(qp + 16 * ks);
     if (c != 1.0f) {  // q not pre-scaled by the producer (generic nova_attn_fwd callers)
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (__bf16)((float)qf[ks][j] * c);
+        for (int j = 0; j < 4; ++j) {
+          const f2v t = Half16<E>::unpack(qf[ks][j]);
+          qf[ks][j] = Half16<E>::pack(t[0] * c, t[1] * c);
+        }
     }
   }
 
@@ -148,10 +151,10 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
       const int row = kb * 32 + r;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        bf8v kf;
-        if (ks < 4) kf = *reinterpret_cast<const bf8v*>(tk + row * 128 + (((2 * ks + hh) ^ ((row >> 1) & 7)) << 4));
-        else kf = *reinterpret_cast<const bf8v*>(tk32 + row * 64 + (((2 * (ks - 4) + hh) ^ ((row >> 2) & 3)) << 4));
-        st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? negm : st[kb], 0, 0, 0);
+        u4v kf;
+        if (ks < 4) kf = *reinterpret_cast<const u4v*>(tk + row * 128 + (((2 * ks + hh) ^ ((row >> 1) & 7)) << 4));
+        else kf = *reinterpret_cast<const u4v*>(tk32 + row * 64 + (((2 * (ks - 4) + hh) ^ ((row >> 2) & 3)) << 4));
+        st[kb] = Half16<E>::mfma32(kf, qf[ks], ks == 0 ? negm : st[kb]);
       }
     }
     if (kt == nkt - 1 && (Lk & (A_KV - 1)) != 0) {  // ragged last tile: keys >= Lk contribute nothing
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
       for (int i = 0; i < 16; ++i) { st[0][i] -= delta; st[1][i] -= delta; negm[i] = -m_run; }
     }
     float psum = 0.f;
-    bf8v pb[2][2];
+    u4v pb[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -201,10 +204,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
           const float p0 = __builtin_amdgcn_exp2f(st[kb][8 * s2 + 2 * j]);
           const float p1 = __builtin_amdgcn_exp2f(st[kb][8 * s2 + 2 * j + 1]);
           psum += p0 + p1;
-          const bf2v h = __builtin_convertvector(f2v{p0, p1}, bf2v);
-          packed[j] = __builtin_bit_cast(uint32_t, h);
+          packed[j] = Half16<E>::pack(p0, p1);
         }
-        pb[kb][s2] = __builtin_bit_cast(bf8v, packed);
+        pb[kb][s2] = packed;
       }
     l_run += psum;
 
@@ -229,8 +231,8 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
           }
           const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
           const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a1);
-          const bf8v vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          ot[dvb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kb][s2], ot[dvb], 0, 0, 0);
+          const u4v vf = __builtin_bit_cast(u4v, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          ot[dvb] = Half16<E>::mfma32(vf, pb[kb][s2], ot[dvb]);
         }
     }
   }
@@ -242,14 +244,14 @@ __global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_bf16(const bf16_t*
   if (qrow < Lq) {
     // training: log2-domain log-sum-exp of the row's scaled scores, what the backward kernels rebuild P from (attn_bwd.hip)
     if (LSE && hh == 0) lse[((size_t)s * heads + head) * Lq + qrow] = m_run + __log2f(l_tot);
-    bf16_t* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD;
+    E* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD;
 #pragma unroll
     for (int dvb = 0; dvb < NDV; ++dvb)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int dv = dvb * 32 + 8 * g + 4 * hh;
-        u2v pk = {pack_bf2(ot[dvb][4 * g] * inv, ot[dvb][4 * g + 1] * inv),
-                  pack_bf2(ot[dvb][4 * g + 2] * inv, ot[dvb][4 * g + 3] * inv)};
+        u2v pk = {Half16<E>::pack(ot[dvb][4 * g] * inv, ot[dvb][4 * g + 1] * inv),
+                  Half16<E>::pack(ot[dvb][4 * g + 2] * inv, ot[dvb][4 * g + 3] * inv)};
         *reinterpret_cast<u2v*>(op + dv) = pk;
       }
   }
@@ -397,8 +399,8 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (S <= 0 || Lq <= 0) return 0;
   if (hd != 64 && hd != 96) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64 and 96)", hd);
   if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
-  if (lse && dtype != NOVA_BF16) return set_error(NOVA_ERR_ARG, "attn_fwd: the log-sum-exp output is built for the bf16 kernel");
-  const int align = dtype == NOVA_BF16 ? 8 : 4;  // 16-byte row alignment for the vector loads
+  if (lse && !dtype_is16(dtype)) return set_error(NOVA_ERR_ARG, "attn_fwd: the log-sum-exp output is built for the 16-bit kernels");
+  const int align = dtype_is16(dtype) ? 8 : 4;  // 16-byte row alignment for the vector loads
   if (q_rs % align || kv_rs % align || o_rs % align) return set_error(NOVA_ERR_SHAPE, "attn_fwd: row strides must be 16-byte multiples");
   if (kv_ss == 0) kv_ss = (long)Lk * kv_rs;
   if (kv_ss % align || kv_ss < (long)Lk * kv_rs) return set_error(NOVA_ERR_SHAPE, "attn_fwd: kv sequence stride must cover Lk rows and be a 16-byte multiple");
@@ -407,16 +409,21 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   const float c = scale * 1.4426950408889634f;
   dim3 grid(nq, heads, S), block(256), grid1((unsigned)((long)nq * heads * S));
   ProfScope prof(PROF_ATTN, 4.0 * S * heads * (double)Lq * Lk * hd, st);
-  if (dtype == NOVA_BF16) {
+  if (dtype_is16(dtype)) {
     const float cl = q_prescaled ? 1.0f : c;
-    const bf16_t *qq = (const bf16_t*)q, *kk = (const bf16_t*)k, *vv = (const bf16_t*)v;
     const int rev = walk_is_reverse() ? 1 : 0;
     if (hd == 64 && attn_variant() != 0)
-      return attn_fwd_m16(qq, kk, vv, (bf16_t*)o, S, heads, Lq, Lk, q_rs, kv_rs, o_rs, cl, st, kv_ss, lse, (attn_variant() & 1) && attn_variant() != 5 ? 32 : 64, attn_variant() >= 3, attn_variant() == 5);
-    if (lse && hd == 64) hipLaunchKernelGGL((attn_bf16<64, true>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
-    else if (lse) hipLaunchKernelGGL((attn_bf16<96, true>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
-    else if (hd == 64) hipLaunchKernelGGL((attn_bf16<64, false>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
-    else hipLaunchKernelGGL((attn_bf16<96, false>), grid1, block, 0, st, qq, kk, vv, (bf16_t*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+      return attn_fwd_m16(q, k, v, o, S, heads, Lq, Lk, q_rs, kv_rs, o_rs, cl, dtype, st, kv_ss, lse, (attn_variant() & 1) && attn_variant() != 5 ? 32 : 64,
+                          attn_variant() >= 3, attn_variant() == 5);
+    dispatch_half(dtype, [&](auto tag) {
+      using E = decltype(tag);
+      const E *qq = (const E*)q, *kk = (const E*)k, *vv = (const E*)v;
+      if (lse && hd == 64) hipLaunchKernelGGL((attn_bf16<E, 64, true>), grid1, block, 0, st, qq, kk, vv, (E*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+      else if (lse) hipLaunchKernelGGL((attn_bf16<E, 96, true>), grid1, block, 0, st, qq, kk, vv, (E*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+      else if (hd == 64) hipLaunchKernelGGL((attn_bf16<E, 64, false>), grid1, block, 0, st, qq, kk, vv, (E*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+      else hipLaunchKernelGGL((attn_bf16<E, 96, false>), grid1, block, 0, st, qq, kk, vv, (E*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+      return 0;
+    });
   } else {
     const float *qq = (const float*)q, *kk = (const float*)k, *vv = (const float*)v;
     if (hd == 64) hipLaunchKernelGGL(attn_f32<64>, grid, block, 0, st, qq, kk, vv, (float*)o, Lq, Lk, q_rs, kv_rs, o_rs, c, kv_ss);

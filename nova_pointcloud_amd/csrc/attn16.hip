@@ -57,9 +57,9 @@ __device__ __forceinline__ float sum_over_g(float x) {
 }
 }  // namespace
 
-template <int NQB, bool LSE, bool SUMM>
-__global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                                         const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+template <typename E, int NQB, bool LSE, bool SUMM>  // E: bf16_t / f16_t (same loads, LDS images and stores; MFMA form and pair packing differ)
+__global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const E* __restrict__ q, const E* __restrict__ k,
+                                                                         const E* __restrict__ v, E* __restrict__ o,
                                                                          int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
                                                                          int heads, int nq, int rev, long kv_ss, float* __restrict__ lse) {
   constexpr int HD = 64, NDS = HD / 32, NDVB = HD / 16, RW = 16 * NQB;
@@ -72,23 +72,26 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf1
   const int head = sh % heads, s = sh / heads;
   const int q0 = qt * (4 * RW) + wid * RW;
 
-  const bf16_t* qb_ = q + (size_t)s * Lq * q_rs + head * HD;
-  const bf16_t* kb_ = k + (size_t)s * kv_ss + head * HD;
-  const bf16_t* vb_ = v + (size_t)s * kv_ss + head * HD;
+  const E* qb_ = q + (size_t)s * Lq * q_rs + head * HD;
+  const E* kb_ = k + (size_t)s * kv_ss + head * HD;
+  const E* vb_ = v + (size_t)s * kv_ss + head * HD;
 
   // Q fragments, B operand of S^T = K Q^T: lane (i, g) holds Q[q0 + 16 qb + i][32 ds + 8 g + 0..7]
-  bf8v qf[NQB][NDS];
+  u4v qf[NQB][NDS];
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
     const int qrow = min(q0 + 16 * qb + i, Lq - 1);
-    const bf16_t* qp = qb_ + (size_t)qrow * q_rs + 8 * g;
+    const E* qp = qb_ + (size_t)qrow * q_rs + 8 * g;
 #pragma unroll
-    for (int ds = 0; ds < NDS; ++ds) qf[qb][ds] = *reinterpret_cast<const bf8v*>(qp + 32 * ds);
+    for (int ds = 0; ds < NDS; ++ds) qf[qb][ds] = *reinterpret_cast<const u4v*>(qp + 32 * ds);
     if (c != 1.0f) {
 #pragma unroll
       for (int ds = 0; ds < NDS; ++ds)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qf[qb][ds][j] = (__bf16)((float)qf[qb][ds][j] * c);
+        for (int j = 0; j < 4; ++j) {
+          const f2v t = Half16<E>::unpack(qf[qb][ds][j]);
+          qf[qb][ds][j] = Half16<E>::pack(t[0] * c, t[1] * c);
+        }
     }
   }
 
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf1
 
   f4v ot[NQB][NDVB], negm[NQB], lacc[NQB];  // lacc (SUMM): row sums of the bf16-rounded P from an all-ones V^T block
   float m_run[NQB], l_run[NQB];
-  const bf8v ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+  const u4v ones = {Half16<E>::ONE2, Half16<E>::ONE2, Half16<E>::ONE2, Half16<E>::ONE2};
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
     m_run[qb] = 0.f;
@@ -156,10 +159,10 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf1
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int ds = 0; ds < NDS; ++ds) {
-        const bf8v kf = *reinterpret_cast<const bf8v*>(tk + kb * 2048 + (ds == 0 ? koff0 : koff1));
+        const u4v kf = *reinterpret_cast<const u4v*>(tk + kb * 2048 + (ds == 0 ? koff0 : koff1));
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
-          st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ds], ds == 0 ? negm[qb] : st[qb][kb], 0, 0, 0);
+          st[qb][kb] = Half16<E>::mfma16(kf, qf[qb][ds], ds == 0 ? negm[qb] : st[qb][kb]);
       }
     }
     if constexpr (FIRST) {
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf1
         for (int kb = 0; kb < 4; ++kb) st[qb][kb] -= delta;
       }
     }
-    bf8v pb[NQB][2];
+    u4v pb[NQB][2];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
       float psum = 0.f;
@@ -216,9 +219,9 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf1
             const float p0 = __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j]);
             const float p1 = __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j + 1]);
             if (!SUMM) psum += p0 + p1;
-            packed[2 * h2 + j] = pack_bf2(p0, p1);
+            packed[2 * h2 + j] = Half16<E>::pack(p0, p1);
           }
-        pb[qb][kp] = __builtin_bit_cast(bf8v, packed);
+        pb[qb][kp] = packed;
       }
       if (!SUMM) l_run[qb] += psum;
     }
@@ -230,13 +233,13 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf1
         const char* a0 = tv + kp * 4096 + voff[dvb];
         const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
         const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(a0 + 2048));
-        const bf8v vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const u4v vf = __builtin_bit_cast(u4v, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) ot[qb][dvb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[qb][kp], ot[qb][dvb], 0, 0, 0);
+        for (int qb = 0; qb < NQB; ++qb) ot[qb][dvb] = Half16<E>::mfma16(vf, pb[qb][kp], ot[qb][dvb]);
       }
       if (SUMM) {
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qb][kp], lacc[qb], 0, 0, 0);
+        for (int qb = 0; qb < NQB; ++qb) lacc[qb] = Half16<E>::mfma16(ones, pb[qb][kp], lacc[qb]);
       }
     }
   };
@@ -261,10 +264,10 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf1
     const int qrow = q0 + 16 * qb + i;
     if (qrow < Lq) {
       if (LSE && g == 0) lse[((size_t)s * heads + head) * Lq + qrow] = m_run[qb] + __log2f(l_tot);
-      bf16_t* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD + 4 * g;
+      E* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD + 4 * g;
 #pragma unroll
       for (int dvb = 0; dvb < NDVB; ++dvb) {
-        u2v pk = {pack_bf2(ot[qb][dvb][0] * inv, ot[qb][dvb][1] * inv), pack_bf2(ot[qb][dvb][2] * inv, ot[qb][dvb][3] * inv)};
+        u2v pk = {Half16<E>::pack(ot[qb][dvb][0] * inv, ot[qb][dvb][1] * inv), Half16<E>::pack(ot[qb][dvb][2] * inv, ot[qb][dvb][3] * inv)};
         *reinterpret_cast<u2v*>(op + 16 * dvb) = pk;
       }
     }
@@ -280,9 +283,9 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const bf1
 //   P(t-1)) | { p(t) = exp2(S(t)), pack  ||  O += V(t-1) P(t-1), l += 1 P(t-1) }
 // V lags K by one tile in the LDS ring (V(t) is staged with K(t+1) and read in iteration t+1), so two buffers suffice.
 // Row sums ride on the matrix pipe (all-ones block). Results equal attn_bf16_m16<4, LSE, true> bit for bit.
-template <bool LSE>
-__global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                          const bf16_t* __restrict__ v, bf16_t* __restrict__ o, int Lq, int Lk,
+template <typename E, bool LSE>
+__global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const E* __restrict__ q, const E* __restrict__ k,
+                                                          const E* __restrict__ v, E* __restrict__ o, int Lq, int Lk,
                                                           long q_rs, long kv_rs, long o_rs, float c, int heads, int nq, int rev,
                                                           long kv_ss, float* __restrict__ lse) {
   constexpr int NQB = 4, HD = 64, NDS = 2, NDVB = 4, RW = 64;
@@ -294,9 +297,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
   const int sh = t / nq, qt = t - sh * nq;
   const int head = sh % heads, s = sh / heads;
   const int q0 = qt * (4 * RW) + wid * RW;
-  const bf16_t* qb_ = q + (size_t)s * Lq * q_rs + head * HD;
-  const bf16_t* kb_ = k + (size_t)s * kv_ss + head * HD;
-  const bf16_t* vb_ = v + (size_t)s * kv_ss + head * HD;
+  const E* qb_ = q + (size_t)s * Lq * q_rs + head * HD;
+  const E* kb_ = k + (size_t)s * kv_ss + head * HD;
+  const E* vb_ = v + (size_t)s * kv_ss + head * HD;
 
   // The wave's 64 Q rows live in its own 8 KiB of LDS (K's image and swizzle; written once, read back as B fragments at the
   // top of every tile): 32 registers that the exp / P V block of the pipeline needs more than the score block does.
@@ -305,15 +308,18 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
   for (int qb = 0; qb < NQB; ++qb) {
     const int row = 16 * qb + i;
     const int qrow = min(q0 + row, Lq - 1);
-    const bf16_t* qp = qb_ + (size_t)qrow * q_rs + 8 * g;
+    const E* qp = qb_ + (size_t)qrow * q_rs + 8 * g;
 #pragma unroll
     for (int ds = 0; ds < NDS; ++ds) {
-      bf8v f = *reinterpret_cast<const bf8v*>(qp + 32 * ds);
+      u4v f = *reinterpret_cast<const u4v*>(qp + 32 * ds);
       if (c != 1.0f) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (__bf16)((float)f[j] * c);
+        for (int j = 0; j < 4; ++j) {
+          const f2v t = Half16<E>::unpack(f[j]);
+          f[j] = Half16<E>::pack(t[0] * c, t[1] * c);
+        }
       }
-      *reinterpret_cast<bf8v*>(qs + row * 128 + (((4 * ds + g) ^ ((row >> 1) & 7)) << 4)) = f;
+      *reinterpret_cast<u4v*>(qs + row * 128 + (((4 * ds + g) ^ ((row >> 1) & 7)) << 4)) = f;
     }
   }
 
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
   const uint32_t ck0 = (uint32_t)((scp ^ ((srow0 >> 1) & 7)) << 4), ck1 = (uint32_t)((scp ^ ((srow1 >> 1) & 7)) << 4);
   const uint32_t cv0 = (uint32_t)((scp ^ (((srow0 >> 1) & 3) << 1)) << 4), cv1 = (uint32_t)((scp ^ (((srow1 >> 1) & 3) << 1)) << 4);
   // one image (K or V, chosen by the wave-uniform base / chunk offsets) of tile kt into LDS at dst
-  auto stage1 = [&](const bf16_t* src, char* dst, int kt, uint32_t c0, uint32_t c1) {
+  auto stage1 = [&](const E* src, char* dst, int kt, uint32_t c0, uint32_t c1) {
     const char* base = reinterpret_cast<const char*>(src) + (size_t)kt * B_KV * rowB;
     const int lim = Lk - 1 - kt * B_KV;
     const uint32_t r0 = (uint32_t)min(srow0, lim) * rowB, r1 = (uint32_t)min(srow1, lim) * rowB;  // rows past Lk re-read the last valid row
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
 
   f4v ot[NQB][NDVB], lacc[NQB];
   float m_run[NQB];
-  const bf8v ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+  const u4v ones = {Half16<E>::ONE2, Half16<E>::ONE2, Half16<E>::ONE2, Half16<E>::ONE2};
 #pragma unroll
   for (int qb = 0; qb < NQB; ++qb) {
     m_run[qb] = 0.f;
@@ -356,15 +362,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
   // masking code at all (softmax does not care about key order): step 0 <-> tile nkt - 1, step j >= 1 <-> tile j - 1.
   // Scores of a step minus the carried max, lane-local max, rescale (FIRST: always, sets m; else rare, and O, l and the
   // pending packed P of the previous step move too). `buf` = LDS buffer of the step's K image.
-  auto score_block = [&](auto first, int buf, f4v (&st)[NQB][4], bf8v (&pend)[NQB][2]) {
+  auto score_block = [&](auto first, int buf, f4v (&st)[NQB][4], u4v (&pend)[NQB][2]) {
     constexpr bool FIRST = decltype(first)::value;
     const char* tk = smem + buf * 2 * B_T;
-    bf8v qf[NQB][NDS];
+    u4v qf[NQB][NDS];
     f4v negm[NQB];
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
 #pragma unroll
-      for (int ds = 0; ds < NDS; ++ds) qf[qb][ds] = *reinterpret_cast<const bf8v*>(qs + qb * 2048 + (ds == 0 ? koff0 : koff1));
+      for (int ds = 0; ds < NDS; ++ds) qf[qb][ds] = *reinterpret_cast<const u4v*>(qs + qb * 2048 + (ds == 0 ? koff0 : koff1));
       float nm = -m_run[qb];
       asm volatile("" : "+v"(nm));  // rebuilt per tile: the 4-register -m block is not carried through the exp / P V block
       negm[qb] = f4v{nm, nm, nm, nm};
@@ -373,10 +379,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int ds = 0; ds < NDS; ++ds) {
-        const bf8v kf = *reinterpret_cast<const bf8v*>(tk + kb * 2048 + (ds == 0 ? koff0 : koff1));
+        const u4v kf = *reinterpret_cast<const u4v*>(tk + kb * 2048 + (ds == 0 ? koff0 : koff1));
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
-          st[qb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qb][ds], ds == 0 ? negm[qb] : st[qb][kb], 0, 0, 0);
+          st[qb][kb] = Half16<E>::mfma16(kf, qf[qb][ds], ds == 0 ? negm[qb] : st[qb][kb]);
       }
     }
     if constexpr (FIRST) {
@@ -411,11 +417,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
           for (int d = 0; d < NDVB; ++d) ot[qb][d] *= alpha;
 #pragma unroll
           for (int kp = 0; kp < 2; ++kp) {
-            u4v w = __builtin_bit_cast(u4v, pend[qb][kp]);
+            u4v w = pend[qb][kp];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              w[e] = pack_bf2(__uint_as_float(w[e] << 16) * alpha, __uint_as_float(w[e] & 0xffff0000u) * alpha);
-            pend[qb][kp] = __builtin_bit_cast(bf8v, w);
+            for (int e = 0; e < 4; ++e) {
+              const f2v t = Half16<E>::unpack(w[e]);
+              w[e] = Half16<E>::pack(t[0] * alpha, t[1] * alpha);
+            }
+            pend[qb][kp] = w;
           }
         }
         m_run[qb] += delta;
@@ -425,30 +433,30 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
     }
   };
   // p = exp2(s), two per v_cvt_pk: the 8 probabilities of (qb, kp) in the B-operand order of the P V product
-  auto exp_pack = [&](const f4v (&st)[NQB][4], int qb, int kp) -> bf8v {
+  auto exp_pack = [&](const f4v (&st)[NQB][4], int qb, int kp) -> u4v {
     u4v packed;
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        packed[2 * h2 + j] = pack_bf2(__builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j]), __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j + 1]));
-    return __builtin_bit_cast(bf8v, packed);
+        packed[2 * h2 + j] = Half16<E>::pack(__builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j]), __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j + 1]));
+    return packed;
   };
   // O^T += V^T(tile) P^T for one (kp, dvb): one transposed fragment, NQB MFMAs
-  auto pv_step = [&](const char* tv, const bf8v (&pend)[NQB][2], int kp, int dvb) {
+  auto pv_step = [&](const char* tv, const u4v (&pend)[NQB][2], int kp, int dvb) {
     const char* a0 = tv + kp * 4096 + voff[dvb];
     const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
     const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(a0 + 2048));
-    const bf8v vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    const u4v vf = __builtin_bit_cast(u4v, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) ot[qb][dvb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pend[qb][kp], ot[qb][dvb], 0, 0, 0);
+    for (int qb = 0; qb < NQB; ++qb) ot[qb][dvb] = Half16<E>::mfma16(vf, pend[qb][kp], ot[qb][dvb]);
   };
-  auto sum_step = [&](const bf8v (&pend)[NQB][2], int kp) {
+  auto sum_step = [&](const u4v (&pend)[NQB][2], int kp) {
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pend[qb][kp], lacc[qb], 0, 0, 0);
+    for (int qb = 0; qb < NQB; ++qb) lacc[qb] = Half16<E>::mfma16(ones, pend[qb][kp], lacc[qb]);
   };
 
-  bf8v pbp[NQB][2];  // packed P of the previous step, pending its P V product
+  u4v pbp[NQB][2];  // packed P of the previous step, pending its P V product
   auto tile_of = [&](int step) { return step == 0 ? nkt - 1 : step - 1; };
   // ---- prologue: step 0 (the last tile) up to its packed P. Ring: K(step) in buffer step & 1, V(step) likewise; V lags K
   // by one step (staged with K(step + 1), read during step + 1).
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
     const char* tv = smem + ((j + 1) & 1) * 2 * B_T + B_T;  // V(step j - 1)
     f4v st[NQB][4];
     score_block(std::false_type{}, j & 1, st, pbp);
-    bf8v pbn[NQB][2];
+    u4v pbn[NQB][2];
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
 #pragma unroll
@@ -509,37 +517,43 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const bf16_t* __restric
     const int qrow = q0 + 16 * qb + i;
     if (qrow < Lq) {
       if (LSE && g == 0) lse[((size_t)s * heads + head) * Lq + qrow] = m_run[qb] + __log2f(l_tot);
-      bf16_t* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD + 4 * g;
+      E* op = o + ((size_t)s * Lq + qrow) * o_rs + head * HD + 4 * g;
 #pragma unroll
       for (int dvb = 0; dvb < NDVB; ++dvb) {
-        u2v pk = {pack_bf2(ot[qb][dvb][0] * inv, ot[qb][dvb][1] * inv), pack_bf2(ot[qb][dvb][2] * inv, ot[qb][dvb][3] * inv)};
+        u2v pk = {Half16<E>::pack(ot[qb][dvb][0] * inv, ot[qb][dvb][1] * inv), Half16<E>::pack(ot[qb][dvb][2] * inv, ot[qb][dvb][3] * inv)};
         *reinterpret_cast<u2v*>(op + 16 * dvb) = pk;
       }
     }
   }
 }
 
-// rows_per_wave 32 or 64; head_dim 64, bf16 only (attn_fwd in attn.hip checks shapes and strides before it dispatches here)
-int attn_fwd_m16(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, int S, int heads, int Lq, int Lk, long q_rs, long kv_rs,
-                 long o_rs, float cl, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined) {
+// rows_per_wave 32 or 64; head_dim 64; dtype NOVA_BF16 or NOVA_F16 (attn_fwd in attn.hip checks shapes and strides before it dispatches here)
+int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, long q_rs, long kv_rs,
+                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined) {
   const int rw = rows_per_wave == 64 ? 64 : 32;
   const int nq = (Lq + 4 * rw - 1) / (4 * rw);
   if ((long)nq * heads * S > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
   dim3 block(256), grid((unsigned)((long)nq * heads * S));
   const int rev = walk_is_reverse() ? 1 : 0;
-#define NOVA_A16(NQB_, SUMM_)                                                                                                        \
-  do {                                                                                                                              \
-    if (lse) hipLaunchKernelGGL((attn_bf16_m16<NQB_, true, SUMM_>), grid, block, 0, st, q, k, v, o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse); \
-    else hipLaunchKernelGGL((attn_bf16_m16<NQB_, false, SUMM_>), grid, block, 0, st, q, k, v, o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);    \
+  dispatch_half(dtype, [&](auto tag) {
+    using E = decltype(tag);
+    const E *qq = (const E*)q, *kk = (const E*)k, *vv = (const E*)v;
+    E* oo = (E*)o;
+#define NOVA_A16(NQB_, SUMM_)                                                                                                       \
+  do {                                                                                                                             \
+    if (lse) hipLaunchKernelGGL((attn_bf16_m16<E, NQB_, true, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse); \
+    else hipLaunchKernelGGL((attn_bf16_m16<E, NQB_, false, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);    \
   } while (0)
-  if (pipelined) {
-    if (lse) hipLaunchKernelGGL((attn_bf16_m16p<true>), grid, block, 0, st, q, k, v, o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
-    else hipLaunchKernelGGL((attn_bf16_m16p<false>), grid, block, 0, st, q, k, v, o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
-  } else if (rw == 32 && !sum_on_mfma) NOVA_A16(2, false);
-  else if (rw == 32) NOVA_A16(2, true);
-  else if (!sum_on_mfma) NOVA_A16(4, false);
-  else NOVA_A16(4, true);
+    if (pipelined) {
+      if (lse) hipLaunchKernelGGL((attn_bf16_m16p<E, true>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+      else hipLaunchKernelGGL((attn_bf16_m16p<E, false>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+    } else if (rw == 32 && !sum_on_mfma) NOVA_A16(2, false);
+    else if (rw == 32) NOVA_A16(2, true);
+    else if (!sum_on_mfma) NOVA_A16(4, false);
+    else NOVA_A16(4, true);
 #undef NOVA_A16
+    return 0;
+  });
   return check_launch("attn_fwd_m16");
 }
 

@@ -62,8 +62,8 @@ ProfScope::~ProfScope() {
   if (idx < (int)g_prof.size()) (void)hipEventRecord(g_prof[idx].b, st);
 }
 
-static inline bool bad_dtype(int dtype) { return dtype != NOVA_F32 && dtype != NOVA_BF16; }
-static inline size_t esize(int dtype) { return dtype == NOVA_BF16 ? 2 : 4; }
+static inline bool bad_dtype(int dtype) { return dtype != NOVA_F32 && dtype != NOVA_BF16 && dtype != NOVA_F16; }
+static inline size_t esize(int dtype) { return dtype_is16(dtype) ? 2 : 4; }
 
 }  // namespace nova
 
@@ -212,11 +212,12 @@ int nova_row_norm(const void* in, void* out, const float* gamma, const float* be
 
 int nova_row_norm_chain(const void* g, const void* x, const float* gamma, const float* beta, const void* mod, long mod_ld,
                         int gate_off, int scale_off, int shift_off, float eps_first, float eps_second, void* x_new_out,
-                        void* h_out, long rows, int D, void* stream) {
+                        void* h_out, long rows, int D, int dtype, void* stream) {
+  NOVA_REQUIRE(dtype_is16(dtype), NOVA_ERR_ARG, "row_norm_chain: dtype %d is not a 16-bit storage type", dtype);
   NOVA_REQUIRE(rows == 0 || (g && x && mod && h_out), NOVA_ERR_ARG, "row_norm_chain: null pointer");
   RowNormArgs a2{g, nullptr, gamma, beta, mod, mod_ld, -1, -1, gate_off, x, nullptr, rows, D, eps_first};
   RowNormArgs a1{nullptr, h_out, nullptr, nullptr, mod, mod_ld, scale_off, shift_off, -1, nullptr, nullptr, rows, D, eps_second};
-  return row_norm_chain(a2, a1, x_new_out, (hipStream_t)stream);
+  return row_norm_chain(a2, a1, x_new_out, dtype, (hipStream_t)stream);
 }
 
 int nova_adaln_fc1(const void* x, const void* mod, long mod_ld, int scale_off, int shift_off, float eps, const void* w,
@@ -298,8 +299,8 @@ static int vit_blocks(const nova_vit_block* blocks, int nblocks, void* x, int S,
   } walk;
   for (int i = 0; i < nblocks; ++i) {
     const nova_vit_block& b = blocks[i];
-    // bf16: the softmax scale (in the exp2 domain) is folded into q by the QKV epilogue, before the bf16 rounding
-    const bool pre = dtype == NOVA_BF16;
+    // bf16 / f16: the softmax scale (in the exp2 domain) is folded into q by the QKV epilogue, before the 16-bit rounding
+    const bool pre = dtype_is16(dtype);
     walk.next();
     NOVA_TRY(gemm_qkv_rope(x, b.qkv_w, b.qkv_b, rope, ws_qkv, S, L, D, heads, rope_batch, dtype, st,
                            pre ? scale * 1.4426950408889634f : 1.0f));
@@ -512,10 +513,10 @@ static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, con
       NOVA_TRY(gemm_bias_act(ws_f, blk.fc2_w, blk.fc2_b, ws_g, (int)rows, D, D, NOVA_ACT_NONE, dtype, st));
       RowNormArgs m2{ws_g, ws_u, blk.norm2_w, blk.norm2_b, ws_mod, mod_ld, -1, -1, b * 3 * D + 2 * D, ws_u, nullptr, rows, D, 1e-5f};
       RowNormArgs mf{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, depth * 3 * D, depth * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
-      if (b == depth - 1 && dtype == NOVA_BF16) {
+      if (b == depth - 1 && dtype_is16(dtype)) {
         // last block: its gated norm + residual and the final layer's modulate in ONE row pass (x itself is not needed
         // any more, so it is neither written nor read back); bit-identical to the two launches (rownorm.h)
-        NOVA_TRY(row_norm_chain(m2, mf, nullptr, st));
+        NOVA_TRY(row_norm_chain(m2, mf, nullptr, dtype, st));
       } else {
         NOVA_TRY(row_norm(m2, dtype, st));
         if (b == depth - 1) NOVA_TRY(row_norm(mf, dtype, st));

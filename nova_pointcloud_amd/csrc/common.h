@@ -17,6 +17,12 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u4v;
 typedef __attribute__((ext_vector_type(2))) uint32_t u2v;
 
 typedef uint16_t bf16_t;  // storage type for bf16 tensors
+// storage type for IEEE half tensors (NOVA_F16, the default precision of the reference's callers: scripts/app_nova_t2i.py:36):
+// a distinct 2-byte type so that every kernel template instantiates for it beside bf16_t
+struct f16_t { uint16_t bits; };
+typedef __attribute__((ext_vector_type(8))) _Float16 h8v;
+typedef __attribute__((ext_vector_type(4))) _Float16 h4v;
+typedef __attribute__((ext_vector_type(2))) _Float16 h2v;
 
 #define NOVA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -49,13 +55,51 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, h);
 }
 
+// two floats -> one dword of two halves, round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950; out-of-range values become
+// infinities exactly as torch's .half() makes them)
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  const h2v h = __builtin_convertvector(f2v{lo, hi}, h2v);
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float h2f(uint16_t bits) { return (float)__builtin_bit_cast(_Float16, bits); }
+// the two halves of a dword as floats
+__device__ __forceinline__ f2v unpack_h2(uint32_t u) { return __builtin_convertvector(__builtin_bit_cast(h2v, u), f2v); }
+
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <> __device__ __forceinline__ float to_f<f16_t>(f16_t v) { return h2f(v.bits); }
 
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ f16_t from_f<f16_t>(float v) { return f16_t{__builtin_bit_cast(uint16_t, (_Float16)v)}; }
+
+// 16-bit storage types: pair packing / unpacking and the MFMA that consumes 8-element fragments of them (held as u4v: the
+// two types share every load, LDS image and store; only these three operations differ)
+template <typename T> struct Half16;
+template <> struct Half16<bf16_t> {
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) { return pack_bf2(lo, hi); }
+  static __device__ __forceinline__ f2v unpack(uint32_t u) { return f2v{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+  static __device__ __forceinline__ f4v mfma16(u4v a, u4v b, f4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f16v mfma32(u4v a, u4v b, f16v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+  }
+  static constexpr uint32_t ONE2 = 0x3f803f80u;  // two ones
+};
+template <> struct Half16<f16_t> {
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) { return pack_h2(lo, hi); }
+  static __device__ __forceinline__ f2v unpack(uint32_t u) { return unpack_h2(u); }
+  static __device__ __forceinline__ f4v mfma16(u4v a, u4v b, f4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f16v mfma32(u4v a, u4v b, f16v c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+  }
+  static constexpr uint32_t ONE2 = 0x3c003c00u;
+};
 
 // Wave-wide sum / max, every lane ending with the same value, without the LDS crossbar: __shfl_xor compiles to
 // ds_bpermute_b32 (an LDS-pipe round trip per step, six steps); here four steps are DPP operands of the add itself

@@ -37,12 +37,12 @@ struct GemmEpi {
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_SILU = 2, EPI_ROPE = 3 };
 
 template <typename T> struct Frag;   // one 16-byte LDS read = the per-lane K slice of a fragment
-template <> struct Frag<bf16_t> { bf8v v; };
+template <> struct Frag<bf16_t> { u4v v; };
+template <> struct Frag<f16_t> { u4v v; };
 template <> struct Frag<float> { f4v v; };
 
-__device__ __forceinline__ f4v mma(const Frag<bf16_t>& w, const Frag<bf16_t>& a, f4v c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, c, 0, 0, 0);
-}
+__device__ __forceinline__ f4v mma(const Frag<bf16_t>& w, const Frag<bf16_t>& a, f4v c) { return Half16<bf16_t>::mfma16(w.v, a.v, c); }
+__device__ __forceinline__ f4v mma(const Frag<f16_t>& w, const Frag<f16_t>& a, f4v c) { return Half16<f16_t>::mfma16(w.v, a.v, c); }
 __device__ __forceinline__ f4v mma(const Frag<float>& w, const Frag<float>& a, f4v c) {
   // 4 exact-f32 MFMAs; lane group g = lane>>4 supplies k-slot g of each, so the logical k of
   // (chunk, j) is 4*chunk + j on BOTH operands (any consistent k order is a valid contraction).
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
         if (n0 < e.q_cols) v = v * e.q_scale;  // tile-uniform like `rot`
       }
       if constexpr (sizeof(T) == 2) {
-        u2v o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        u2v o = {Half16<T>::pack(v[0], v[1]), Half16<T>::pack(v[2], v[3])};
         *reinterpret_cast<u2v*>(dst + nf * 16) = o;
       } else {
         *reinterpret_cast<f4v*>(dst + nf * 16) = v;
@@ -250,7 +250,7 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
   if (g_force_tile >= 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
   if (can256 && (g_force_tile >= 256 || (g_force_tile == 0 && M >= 4096)))
     return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols, e.q_scale, e.q_cols,
-                          sizeof(T) == 2 ? NOVA_BF16 : NOVA_F32, st, g_force_tile == 257);
+                          dtype_of<T>(), st, g_force_tile == 257);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(ntm * ntn), block(256);
   ProfScope prof(PROF_GEMM_SMALL, 2.0 * M * N * K, st);
@@ -271,16 +271,15 @@ int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, in
                   int dtype, hipStream_t st) {
   GemmEpi e{bias, nullptr, 1, 1, 2, 0, 1.0f, 0};
   if (act < 0 || act > 2) return set_error(NOVA_ERR_ARG, "gemm: unknown activation %d", act);
-  if (dtype == NOVA_BF16 && (g_force_tile == 16 || (g_force_tile == 0 && skinny_gemm_fits(M, N, K, false))))
-    return skinny_gemm(A, W, bias, out, M, N, K, act, nullptr, st);
-  return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(A, W, out, M, N, K, act, e, st)
-                            : launch_gemm<float>(A, W, out, M, N, K, act, e, st);
+  if (dtype_is16(dtype) && (g_force_tile == 16 || (g_force_tile == 0 && skinny_gemm_fits(M, N, K, false))))
+    return skinny_gemm(A, W, bias, out, M, N, K, act, nullptr, dtype, st);
+  return dispatch_dtype(dtype, [&](auto tag) { return launch_gemm<decltype(tag)>(A, W, out, M, N, K, act, e, st); });
 }
 
 int gemm_modulate_act(const RowNormArgs& pro, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                       int dtype, hipStream_t st) {
-  if (dtype == NOVA_BF16 && (g_force_tile == 16 || (g_force_tile == 0 && skinny_gemm_fits(M, N, K, true))))
-    return skinny_gemm(nullptr, W, bias, out, M, N, K, act, &pro, st);
+  if (dtype_is16(dtype) && (g_force_tile == 16 || (g_force_tile == 0 && skinny_gemm_fits(M, N, K, true))))
+    return skinny_gemm(nullptr, W, bias, out, M, N, K, act, &pro, dtype, st);
   if (int rc = row_norm(pro, dtype, st)) return rc;
   return gemm_bias_act(pro.out, W, bias, out, M, N, K, act, dtype, st);
 }
@@ -292,8 +291,7 @@ int gemm_qkv_rope(const void* x, const void* Wqkv, const float* bias, const floa
   const int epi = (rope || q_scale != 1.0f) ? EPI_ROPE : EPI_NONE;
   if (rope && rope_batch <= 0) return set_error(NOVA_ERR_ARG, "qkv_rope: rope_batch must be > 0");
   GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, rope ? 2 * D : 0, q_scale, q_scale != 1.0f ? D : 0};
-  return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st)
-                            : launch_gemm<float>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st);
+  return dispatch_dtype(dtype, [&](auto tag) { return launch_gemm<decltype(tag)>(x, Wqkv, qkv, S * L, 3 * D, D, epi, e, st); });
 }
 
 int gemm_rope_cols(const void* x, const void* W, const float* bias, const float* rope, void* out, int M, int N, int K,
@@ -301,7 +299,7 @@ int gemm_rope_cols(const void* x, const void* W, const float* bias, const float*
   if (rope && rope_batch <= 0) return set_error(NOVA_ERR_ARG, "rope_cols: rope_batch must be > 0");
   GemmEpi e{bias, rope, L, rope ? rope_batch : 1, hd, rope_cols, 1.0f, 0};
   const int epi = rope ? EPI_ROPE : EPI_NONE;
-  return dtype == NOVA_BF16 ? launch_gemm<bf16_t>(x, W, out, M, N, K, epi, e, st) : launch_gemm<float>(x, W, out, M, N, K, epi, e, st);
+  return dispatch_dtype(dtype, [&](auto tag) { return launch_gemm<decltype(tag)>(x, W, out, M, N, K, epi, e, st); });
 }
 
 }  // namespace nova

@@ -57,7 +57,8 @@ struct GemmEpi256 {
 enum { E_NONE = 0, E_GELU = 1, E_SILU = 2, E_ROPE = 3, E_GELU_Q8 = 5 };
 
 template <typename T> struct PFrag;
-template <> struct PFrag<bf16_t> { bf8v v; };
+template <> struct PFrag<bf16_t> { u4v v; };
+template <> struct PFrag<f16_t> { u4v v; };
 template <> struct PFrag<float> { f4v v; };
 typedef uint8_t fp8_t;  // OCP e4m3 storage (MX-fp8 path: 128 elements per 128-byte K-tile row)
 template <> struct PFrag<fp8_t> { u4v v; };
@@ -65,9 +66,8 @@ typedef __attribute__((ext_vector_type(8))) int i8v;
 template <typename T> struct OutOf { typedef T type; };
 template <> struct OutOf<fp8_t> { typedef bf16_t type; };  // fp8 operands produce bf16 results
 
-__device__ __forceinline__ f4v pmma(const PFrag<bf16_t>& w, const PFrag<bf16_t>& a, f4v c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, c, 0, 0, 0);
-}
+__device__ __forceinline__ f4v pmma(const PFrag<bf16_t>& w, const PFrag<bf16_t>& a, f4v c) { return Half16<bf16_t>::mfma16(w.v, a.v, c); }
+__device__ __forceinline__ f4v pmma(const PFrag<f16_t>& w, const PFrag<f16_t>& a, f4v c) { return Half16<f16_t>::mfma16(w.v, a.v, c); }
 __device__ __forceinline__ f4v pmma(const PFrag<float>& w, const PFrag<float>& a, f4v c) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[j], a.v[j], c, 0, 0, 0);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
         if (n0 < e.q_cols) v = v * e.q_scale;
       }
       if constexpr (sizeof(T) == 2) {
-        pk[nf] = u2v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        pk[nf] = u2v{Half16<T>::pack(v[0], v[1]), Half16<T>::pack(v[2], v[3])};
       } else {
         *reinterpret_cast<f4v*>(dst + nf * 16) = v;
       }
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
             v = v * qmul;
           }
           if constexpr (sizeof(OT) == 2) {
-            pk[nf] = u2v{pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            pk[nf] = u2v{Half16<OT>::pack(v[0], v[1]), Half16<OT>::pack(v[2], v[3])};
           } else {
             *reinterpret_cast<f4v*>(C + (size_t)m * N + cn0 + wc * 64 + fg * 4 + nf * 16) = v;
           }
@@ -794,8 +794,7 @@ int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, i
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
                    hipStream_t st, bool one_tile_per_workgroup) {
   GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, walk_is_reverse() ? 1 : 0, nullptr, nullptr, g_stagger256};
-  return dtype == NOVA_BF16 ? launch256<bf16_t>(A, W, C, M, N, K, epi, e, st, one_tile_per_workgroup)
-                            : launch256<float>(A, W, C, M, N, K, epi, e, st, one_tile_per_workgroup);
+  return dispatch_dtype(dtype, [&](auto tag) { return launch256<decltype(tag)>(A, W, C, M, N, K, epi, e, st, one_tile_per_workgroup); });
 }
 
 }  // namespace nova

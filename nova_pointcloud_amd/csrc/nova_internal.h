@@ -3,7 +3,19 @@
 #include <hip/hip_runtime.h>
 #include "../../include/nova_hip.h"
 
+#include "common.h"
+
 namespace nova {
+
+// storage dtype code <-> element type. Every dtype-generic launcher goes through dispatch_dtype, so a new storage type is
+// one more branch here plus the traits in common.h.
+template <typename T> constexpr int dtype_of() { return sizeof(T) == 4 ? NOVA_F32 : NOVA_BF16; }
+template <> constexpr int dtype_of<f16_t>() { return NOVA_F16; }
+inline bool dtype_is16(int dtype) { return dtype == NOVA_BF16 || dtype == NOVA_F16; }
+template <typename F> inline auto dispatch_dtype(int dtype, F&& f) {
+  return dtype == NOVA_BF16 ? f(bf16_t{}) : dtype == NOVA_F16 ? f(f16_t{}) : f(float{});
+}
+template <typename F> inline auto dispatch_half(int dtype, F&& f) { return dtype == NOVA_F16 ? f(f16_t{}) : f(bf16_t{}); }
 
 // thread-local last-error record; returns `code` so callers can `return set_error(...)`.
 int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
@@ -43,8 +55,8 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
              long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st,
              bool q_prescaled = false, long kv_seq_stride = 0, float* lse = nullptr);
 // attn16.hip: the same attention on the 16x16x32 MFMA shape (bf16, head_dim 64), 32 or 64 query rows per wave
-int attn_fwd_m16(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int S, int heads, int Lq, int Lk, long q_rs,
-                 long kv_rs, long o_rs, float cl, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined = false);
+int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, long q_rs, long kv_rs,
+                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined = false);
 constexpr int NOVA_ATTN_DEFAULT_VARIANT = 3;  // 16x16x32, 32 rows per wave, row sums on the matrix pipe: +8..11 % over variant 0 at every L measured (profiles/r03_attn_variants.txt)
 int attn_set_variant(int v);  // -1 default, 0 .. 5 (attn.hip); -1 returned for other values
 int attn_variant();
@@ -75,12 +87,12 @@ struct RowNormArgs {
 };
 int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
 
-// ---- skinny.hip: small-M GEMM (bf16, K in {768, 1024}), bit-identical to the tile kernels; optional AdaLN-modulate prologue
+// ---- skinny.hip: small-M GEMM (bf16 / f16, K in {768, 1024}), bit-identical to the tile kernels; optional AdaLN-modulate prologue
 bool skinny_gemm_fits(int M, int N, int K, bool modulate);
 void skinny_force_row_blocks(int rb);  // calling thread: 1 / 2 / 4 = rows per workgroup 16 / 32 / 64 for plain launches, 0 = by rule
 int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
-                const RowNormArgs* pro, hipStream_t st);
-int row_norm_chain(const RowNormArgs& a2, const RowNormArgs& a1, void* x_new_out, hipStream_t st);  // rowops.hip, bf16: two chained norms, one pass
+                const RowNormArgs* pro, int dtype, hipStream_t st);
+int row_norm_chain(const RowNormArgs& a2, const RowNormArgs& a1, void* x_new_out, int dtype, hipStream_t st);  // rowops.hip, bf16 / f16: two chained norms, one pass
 // out = act(modulate(pro) W^T + bias): one launch where skinny.hip applies, else row_norm into pro.out followed by the GEMM
 int gemm_modulate_act(const RowNormArgs& pro, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                       int dtype, hipStream_t st);

@@ -21,30 +21,28 @@ template <> struct Chunk<float> {
   __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<f4v*>(p) = v[0]; }
   __device__ __forceinline__ Chunk rounded() const { return *this; }
 };
-template <> struct Chunk<bf16_t> {
+// 16-bit storage types (bf16_t / f16_t): 8 values per 16 bytes
+template <typename T> struct Chunk16 {
   static constexpr int N = 8;
   typedef u4v Raw;
   f4v v[2];
-  static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *reinterpret_cast<const u4v*>(p); }
-  static __device__ __forceinline__ Chunk load(const bf16_t* p) { return from_raw(load_raw(p)); }
-  static __device__ __forceinline__ Chunk from_raw(Raw u) {
-    Chunk c;
-    c.v[0] = f4v{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
-    c.v[1] = f4v{__uint_as_float(u[2] << 16), __uint_as_float(u[2] & 0xffff0000u), __uint_as_float(u[3] << 16), __uint_as_float(u[3] & 0xffff0000u)};
+  static __device__ __forceinline__ Raw load_raw(const T* p) { return *reinterpret_cast<const u4v*>(p); }
+  static __device__ __forceinline__ Chunk<T> load(const T* p) { return from_raw(load_raw(p)); }
+  static __device__ __forceinline__ Chunk<T> from_raw(Raw u) {
+    Chunk<T> c;
+    const f2v a = Half16<T>::unpack(u[0]), b = Half16<T>::unpack(u[1]), d = Half16<T>::unpack(u[2]), e = Half16<T>::unpack(u[3]);
+    c.v[0] = f4v{a[0], a[1], b[0], b[1]};
+    c.v[1] = f4v{d[0], d[1], e[0], e[1]};
     return c;
   }
-  __device__ __forceinline__ void store(bf16_t* p) const {
-    u4v u = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]), pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
-    *reinterpret_cast<u4v*>(p) = u;
+  __device__ __forceinline__ Raw packed() const {
+    return u4v{Half16<T>::pack(v[0][0], v[0][1]), Half16<T>::pack(v[0][2], v[0][3]), Half16<T>::pack(v[1][0], v[1][1]), Half16<T>::pack(v[1][2], v[1][3])};
   }
-  __device__ __forceinline__ Chunk rounded() const {  // the values as they read back after store(): rounded to bf16
-    const u4v u = {pack_bf2(v[0][0], v[0][1]), pack_bf2(v[0][2], v[0][3]), pack_bf2(v[1][0], v[1][1]), pack_bf2(v[1][2], v[1][3])};
-    Chunk c;
-    c.v[0] = f4v{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
-    c.v[1] = f4v{__uint_as_float(u[2] << 16), __uint_as_float(u[2] & 0xffff0000u), __uint_as_float(u[3] << 16), __uint_as_float(u[3] & 0xffff0000u)};
-    return c;
-  }
+  __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<u4v*>(p) = packed(); }
+  __device__ __forceinline__ Chunk<T> rounded() const { return from_raw(packed()); }  // the values as they read back after store()
 };
+template <> struct Chunk<bf16_t> : Chunk16<bf16_t> {};
+template <> struct Chunk<f16_t> : Chunk16<f16_t> {};
 
 // y = LN(in[src])(*gamma + beta)(*(1 + scale) + shift)(*gate)(+ res) for one row held by one wave (reference
 // vision_transformer.py:78-82,91-92 post-norm residual; diffusion_mlp.py:31-36,41-47 AdaLN-Zero modulate / gate).
@@ -137,32 +135,31 @@ __device__ __forceinline__ void row_norm_compute(const RowNormArgs& a, long row,
 // final layer's modulate :96-97): x_new = LN(g) * gamma + beta) * gate + x, stored as bf16, then h = LN(x_new)(1 + scale)
 // + shift. a2 describes the first norm (in = g, res = x, gate_off, gamma / beta), a1 the second (scale_off / shift_off;
 // its `in` is not read). The second norm sees x_new exactly as it would read it back from memory (rounded to bf16), so
-// the chain equals row_norm(a2) followed by row_norm(a1) bit for bit. bf16 rows only.
-template <int NIT>
+// the chain equals row_norm(a2) followed by row_norm(a1) bit for bit. 16-bit rows only.
+template <typename T, int NIT>
 struct RowChainRegs {
-  RowRegs<bf16_t, NIT, true, true> first;
-  RowRegs<bf16_t, NIT, false, true> second;
+  RowRegs<T, NIT, true, true> first;
+  RowRegs<T, NIT, false, true> second;
 };
 
-template <int NIT>
-__device__ __forceinline__ void row_chain_load(const RowNormArgs& a2, const RowNormArgs& a1, long row, int lane, RowChainRegs<NIT>& g) {
-  row_norm_load<bf16_t, NIT, true, true>(a2, row, lane, g.first);
-  row_norm_load<bf16_t, NIT, false, true>(a1, row, lane, g.second, false);
+template <typename T, int NIT>
+__device__ __forceinline__ void row_chain_load(const RowNormArgs& a2, const RowNormArgs& a1, long row, int lane, RowChainRegs<T, NIT>& g) {
+  row_norm_load<T, NIT, true, true>(a2, row, lane, g.first);
+  row_norm_load<T, NIT, false, true>(a1, row, lane, g.second, false);
 }
 
-template <int NIT>
-__device__ __forceinline__ void row_chain_finish(const RowNormArgs& a2, const RowNormArgs& a1, int lane, RowChainRegs<NIT>& g,
-                                                 u4v (&x_new)[NIT], Chunk<bf16_t> (&y)[NIT]) {
-  Chunk<bf16_t> y2[NIT];
-  row_norm_finish<bf16_t, NIT, true, true>(a2, lane, g.first, y2);
+template <typename T, int NIT>
+__device__ __forceinline__ void row_chain_finish(const RowNormArgs& a2, const RowNormArgs& a1, int lane, RowChainRegs<T, NIT>& g,
+                                                 u4v (&x_new)[NIT], Chunk<T> (&y)[NIT]) {
+  Chunk<T> y2[NIT];
+  row_norm_finish<T, NIT, true, true>(a2, lane, g.first, y2);
 #pragma unroll
   for (int it = 0; it < NIT; ++it)
     if ((it * 64 + lane) * 8 < a2.D) {
-      x_new[it] = u4v{pack_bf2(y2[it].v[0][0], y2[it].v[0][1]), pack_bf2(y2[it].v[0][2], y2[it].v[0][3]),
-                      pack_bf2(y2[it].v[1][0], y2[it].v[1][1]), pack_bf2(y2[it].v[1][2], y2[it].v[1][3])};
+      x_new[it] = y2[it].packed();
       g.second.x[it] = x_new[it];
     }
-  row_norm_finish<bf16_t, NIT, false, true>(a1, lane, g.second, y);
+  row_norm_finish<T, NIT, false, true>(a1, lane, g.second, y);
 }
 
 }  // namespace nova

@@ -25,17 +25,19 @@ template <> struct Vec4<float> {
   static __device__ __forceinline__ f4v load(const float* p) { return *reinterpret_cast<const f4v*>(p); }
   static __device__ __forceinline__ void store(float* p, f4v v) { *reinterpret_cast<f4v*>(p) = v; }
 };
-template <> struct Vec4<bf16_t> {
-  static __device__ __forceinline__ f4v load(const bf16_t* p) {
+template <typename T> struct Vec4Half {  // bf16_t / f16_t
+  static __device__ __forceinline__ f4v load(const T* p) {
     const u2v u = *reinterpret_cast<const u2v*>(p);
-    return f4v{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16),
-               __uint_as_float(u[1] & 0xffff0000u)};
+    const f2v a = Half16<T>::unpack(u[0]), b = Half16<T>::unpack(u[1]);
+    return f4v{a[0], a[1], b[0], b[1]};
   }
-  static __device__ __forceinline__ void store(bf16_t* p, f4v v) {
-    u2v u = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+  static __device__ __forceinline__ void store(T* p, f4v v) {
+    u2v u = {Half16<T>::pack(v[0], v[1]), Half16<T>::pack(v[2], v[3])};
     *reinterpret_cast<u2v*>(p) = u;
   }
 };
+template <> struct Vec4<bf16_t> : Vec4Half<bf16_t> {};
+template <> struct Vec4<f16_t> : Vec4Half<f16_t> {};
 
 template <typename T, int NIT, bool HAS_RES, bool HAS_MOD>
 __global__ __launch_bounds__(256) void row_norm_kernel(RowNormArgs a) {
@@ -101,7 +103,7 @@ static void launch_row_norm(const RowNormArgs& a, dim3 grid, hipStream_t st) {
 
 int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
   if (a.rows <= 0) return 0;
-  const int vec = dtype == NOVA_BF16 ? 8 : 4;
+  const int vec = dtype_is16(dtype) ? 8 : 4;
   if (a.D % vec != 0 || a.D > 2048) return set_error(NOVA_ERR_SHAPE, "row_norm: D=%d unsupported (need D %% %d == 0, D <= 2048)", a.D, vec);
   if (a.mod && (a.mod_ld % vec || (a.scale_off >= 0 && (a.scale_off % vec || a.shift_off % vec || a.shift_off < 0)) ||
                 (a.gate_off >= 0 && a.gate_off % vec)))
@@ -112,13 +114,16 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
   RowNormArgs ar = a;
   ar.rev = walk_is_reverse() ? 1 : 0;
   // algorithmic bytes: read in (+res, +mod terms) and write out once
-  const double esz = dtype == NOVA_BF16 ? 2.0 : 4.0;
+  const double esz = dtype_is16(dtype) ? 2.0 : 4.0;
   const int nmod = a.mod ? ((a.scale_off >= 0 ? 2 : 0) + (a.gate_off >= 0 ? 1 : 0)) : 0;
   ProfScope prof(PROF_ROWNORM, esz * a.rows * a.D * (2.0 + (a.res ? 1 : 0) + nmod), st);
   const int chunks = (a.D / vec + 63) / 64;  // 16-byte chunks per lane
-  if (dtype == NOVA_BF16) {
-    if (chunks <= 2) launch_row_norm<bf16_t, 2>(ar, grid, st);
-    else launch_row_norm<bf16_t, 4>(ar, grid, st);
+  if (dtype_is16(dtype)) {
+    dispatch_half(dtype, [&](auto tag) {
+      if (chunks <= 2) launch_row_norm<decltype(tag), 2>(ar, grid, st);
+      else launch_row_norm<decltype(tag), 4>(ar, grid, st);
+      return 0;
+    });
   } else {
     if (chunks <= 4) launch_row_norm<float, 4>(ar, grid, st);
     else launch_row_norm<float, 8>(ar, grid, st);
@@ -126,17 +131,17 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st) {
   return check_launch("row_norm");
 }
 
-template <int NIT>
-__global__ __launch_bounds__(256) void row_norm_chain_kernel(RowNormArgs a2, RowNormArgs a1, bf16_t* __restrict__ x_new_out) {
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void row_norm_chain_kernel(RowNormArgs a2, RowNormArgs a1, T* __restrict__ x_new_out) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a2.rows) return;
-  RowChainRegs<NIT> g;
-  row_chain_load<NIT>(a2, a1, row, lane, g);
+  RowChainRegs<T, NIT> g;
+  row_chain_load<T, NIT>(a2, a1, row, lane, g);
   u4v xn[NIT];
-  Chunk<bf16_t> y[NIT];
-  row_chain_finish<NIT>(a2, a1, lane, g, xn, y);
-  bf16_t* out = static_cast<bf16_t*>(a1.out) + row * a1.D;
+  Chunk<T> y[NIT];
+  row_chain_finish<T, NIT>(a2, a1, lane, g, xn, y);
+  T* out = static_cast<T*>(a1.out) + row * a1.D;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int d = (it * 64 + lane) * 8;
@@ -147,10 +152,11 @@ __global__ __launch_bounds__(256) void row_norm_chain_kernel(RowNormArgs a2, Row
   }
 }
 
-// bf16 rows; a2 = gated affine norm with residual (its `out` is not used: x_new goes to x_new_out when that is given),
+// 16-bit rows; a2 = gated affine norm with residual (its `out` is not used: x_new goes to x_new_out when that is given),
 // a1 = scale / shift modulate writing a1.out. Equals row_norm(a2) then row_norm(a1) bit for bit (rownorm.h).
-int row_norm_chain(const RowNormArgs& a2, const RowNormArgs& a1, void* x_new_out, hipStream_t st) {
+int row_norm_chain(const RowNormArgs& a2, const RowNormArgs& a1, void* x_new_out, int dtype, hipStream_t st) {
   if (a2.rows <= 0) return 0;
+  if (!dtype_is16(dtype)) return set_error(NOVA_ERR_ARG, "row_norm_chain: 16-bit rows only");
   if (a2.D != a1.D || a2.rows != a1.rows || a2.D % 8 || a2.D > 2048) return set_error(NOVA_ERR_SHAPE, "row_norm_chain: bad shapes");
   if (!a2.in || !a2.res || !a2.mod || a2.gate_off < 0 || a2.scale_off >= 0 || a2.gather || !a1.mod || a1.scale_off < 0 || a1.shift_off < 0 ||
       a1.gate_off >= 0 || a1.gamma || a1.res || a1.gather || !a1.out || (a2.gamma == nullptr) != (a2.beta == nullptr))
@@ -159,8 +165,12 @@ int row_norm_chain(const RowNormArgs& a2, const RowNormArgs& a1, void* x_new_out
     return set_error(NOVA_ERR_SHAPE, "row_norm_chain: modulation offsets must be multiples of 8");
   const dim3 grid((unsigned)((a2.rows + 3) / 4));
   ProfScope prof(PROF_ROWNORM, 2.0 * a2.rows * a2.D * 6.0, st);
-  if ((a2.D / 8 + 63) / 64 <= 2) hipLaunchKernelGGL(row_norm_chain_kernel<2>, grid, dim3(256), 0, st, a2, a1, static_cast<bf16_t*>(x_new_out));
-  else hipLaunchKernelGGL(row_norm_chain_kernel<4>, grid, dim3(256), 0, st, a2, a1, static_cast<bf16_t*>(x_new_out));
+  dispatch_half(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    if ((a2.D / 8 + 63) / 64 <= 2) hipLaunchKernelGGL((row_norm_chain_kernel<T, 2>), grid, dim3(256), 0, st, a2, a1, static_cast<T*>(x_new_out));
+    else hipLaunchKernelGGL((row_norm_chain_kernel<T, 4>), grid, dim3(256), 0, st, a2, a1, static_cast<T*>(x_new_out));
+    return 0;
+  });
   return check_launch("row_norm_chain");
 }
 
@@ -230,12 +240,11 @@ int embed_canvas(const float* canvas, const float* mask, const void* w, const fl
   if ((long)B * N <= 0) return 0;
   if (P > 64 || P <= 0) return set_error(NOVA_ERR_SHAPE, "embed_canvas: patch vector length %d unsupported (1..64)", P);
   dim3 grid((unsigned)((long)B * N)), block(256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(embed_canvas_kernel<bf16_t>, grid, block, 0, st, canvas, mask, (const bf16_t*)w, bias,
-                       (const bf16_t*)mask_token, (const bf16_t*)pos_embed, (bf16_t*)z0, N, P, D);
-  else
-    hipLaunchKernelGGL(embed_canvas_kernel<float>, grid, block, 0, st, canvas, mask, (const float*)w, bias,
-                       (const float*)mask_token, (const float*)pos_embed, (float*)z0, N, P, D);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(embed_canvas_kernel<T>, grid, block, 0, st, canvas, mask, (const T*)w, bias, (const T*)mask_token, (const T*)pos_embed, (T*)z0, N, P, D);
+    return 0;
+  });
   return check_launch("embed_canvas");
 }
 
@@ -271,15 +280,14 @@ int build_sequence(const void* prefix, long prefix_seq_rows, const void* tokens,
                    const long long* ids, void* x, int S, int B, int Lp, int n_sel, int D, int dtype, hipStream_t st) {
   const long rows = (long)S * (Lp + n_sel);
   if (rows <= 0) return 0;
-  const int V = dtype == NOVA_BF16 ? 8 : 4;
+  const int V = dtype_is16(dtype) ? 8 : 4;
   if (D % V) return set_error(NOVA_ERR_SHAPE, "build_sequence: D must be a multiple of %d", V);
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(build_sequence_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)prefix, prefix_seq_rows,
-                       (const bf16_t*)tokens, tok_batch_rows, ids, (bf16_t*)x, rows, B, Lp, n_sel, D);
-  else
-    hipLaunchKernelGGL(build_sequence_kernel<float>, grid, block, 0, st, (const float*)prefix, prefix_seq_rows,
-                       (const float*)tokens, tok_batch_rows, ids, (float*)x, rows, B, Lp, n_sel, D);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(build_sequence_kernel<T>, grid, block, 0, st, (const T*)prefix, prefix_seq_rows, (const T*)tokens, tok_batch_rows, ids, (T*)x, rows, B, Lp, n_sel, D);
+    return 0;
+  });
   return check_launch("build_sequence");
 }
 
@@ -305,13 +313,14 @@ int scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B,
                    int dtype, hipStream_t st) {
   const long rows = (long)S * n_prev;
   if (rows <= 0) return 0;
-  const int V = dtype == NOVA_BF16 ? 8 : 4;
+  const int V = dtype_is16(dtype) ? 8 : 4;
   if (D % V) return set_error(NOVA_ERR_SHAPE, "scatter_tokens: D must be a multiple of %d", V);
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(scatter_tokens_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x1, ids, (bf16_t*)x2, rows, B, Lp, N, n_prev, D);
-  else
-    hipLaunchKernelGGL(scatter_tokens_kernel<float>, grid, block, 0, st, (const float*)x1, ids, (float*)x2, rows, B, Lp, N, n_prev, D);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(scatter_tokens_kernel<T>, grid, block, 0, st, (const T*)x1, ids, (T*)x2, rows, B, Lp, N, n_prev, D);
+    return 0;
+  });
   return check_launch("scatter_tokens");
 }
 
@@ -406,10 +415,11 @@ int silu_add_steps(const void* a, const void* vecs, void* out, long rows, int nv
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "silu_add_steps: D %% 4 != 0");
   const long per4 = rows * D / 4, total4 = per4 * nvec;
   const int blocks = (int)((total4 + 255) / 256 > 16384 ? 16384 : (total4 + 255) / 256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(silu_add_steps_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)vecs, (bf16_t*)out, per4, total4, D);
-  else
-    hipLaunchKernelGGL(silu_add_steps_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)vecs, (float*)out, per4, total4, D);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(silu_add_steps_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)a, (const T*)vecs, (T*)out, per4, total4, D);
+    return 0;
+  });
   return check_launch("silu_add_steps");
 }
 
@@ -418,10 +428,11 @@ int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "silu_add_rows: D %% 4 != 0");
   const long total4 = rows * D / 4;
   const int blocks = (int)((total4 + 255) / 256 > 8192 ? 8192 : (total4 + 255) / 256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(silu_add_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)rowvec, (bf16_t*)out, total4, D);
-  else
-    hipLaunchKernelGGL(silu_add_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)a, (const float*)rowvec, (float*)out, total4, D);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(silu_add_rows_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)a, (const T*)rowvec, (T*)out, total4, D);
+    return 0;
+  });
   return check_launch("silu_add_rows");
 }
 
@@ -441,10 +452,11 @@ __global__ void timestep_freq_kernel(const float* __restrict__ t, const float* _
 int timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, hipStream_t st) {
   if (n <= 0) return 0;
   const int total = n * (freq_dim / 2);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(timestep_freq_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, t, freq, (bf16_t*)out, n, freq_dim);
-  else
-    hipLaunchKernelGGL(timestep_freq_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, t, freq, (float*)out, n, freq_dim);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(timestep_freq_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, st, t, freq, (T*)out, n, freq_dim);
+    return 0;
+  });
   return check_launch("timestep_freq");
 }
 
@@ -471,10 +483,11 @@ int patch_embed_rows(const float* x, const void* w, const float* bias, void* out
   if ((long)S * n <= 0) return 0;
   if (P > 64 || P <= 0) return set_error(NOVA_ERR_SHAPE, "patch_embed_rows: patch vector length %d unsupported", P);
   dim3 grid((unsigned)((long)S * n)), block(256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(patch_embed_rows_kernel<bf16_t>, grid, block, 0, st, x, (const bf16_t*)w, bias, (bf16_t*)out, B, n, P, D);
-  else
-    hipLaunchKernelGGL(patch_embed_rows_kernel<float>, grid, block, 0, st, x, (const float*)w, bias, (float*)out, B, n, P, D);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(patch_embed_rows_kernel<T>, grid, block, 0, st, x, (const T*)w, bias, (T*)out, B, n, P, D);
+    return 0;
+  });
   return check_launch("patch_embed_rows");
 }
 
@@ -559,10 +572,11 @@ int head_cfg_step(const void* h, const void* w, const float* bias, float* x, con
   if (sp.extra_kind < 0 || sp.extra_kind > 2) return set_error(NOVA_ERR_ARG, "head_cfg_step: extra_kind must be 0, 1 or 2");
   if (defer && sp.extra_kind && sp.guidance > 1.0f && !extra) return set_error(NOVA_ERR_ARG, "head_cfg_step: deferred 3-pass mode needs the extra buffer");
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(head_cfg_step_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)h, (const bf16_t*)w, bias, x, noise, vhat, cond, extra, rows, B, n, P, D, sp, defer);
-  else
-    hipLaunchKernelGGL(head_cfg_step_kernel<float>, grid, block, 0, st, (const float*)h, (const float*)w, bias, x, noise, vhat, cond, extra, rows, B, n, P, D, sp, defer);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(head_cfg_step_kernel<T>, grid, block, 0, st, (const T*)h, (const T*)w, bias, x, noise, vhat, cond, extra, rows, B, n, P, D, sp, defer);
+    return 0;
+  });
   return check_launch("head_cfg_step");
 }
 
@@ -639,14 +653,15 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const T* __restrict__ qk
 int kv_append(const void* qkv, void* cache, int S, int Lq, int D, long cap, long base, int dtype, hipStream_t st) {
   const long rows = (long)S * Lq;
   if (rows <= 0) return 0;
-  const int V = dtype == NOVA_BF16 ? 8 : 4;
+  const int V = dtype_is16(dtype) ? 8 : 4;
   if (D % V) return set_error(NOVA_ERR_SHAPE, "kv_append: D must be a multiple of %d", V);
   if (base < 0 || base + Lq > cap) return set_error(NOVA_ERR_SHAPE, "kv_append: rows [%ld, %ld) exceed the cache capacity %ld", base, base + Lq, cap);
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(kv_append_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)cache, rows, Lq, D, cap, base);
-  else
-    hipLaunchKernelGGL(kv_append_kernel<float>, grid, block, 0, st, (const float*)qkv, (float*)cache, rows, Lq, D, cap, base);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(kv_append_kernel<T>, grid, block, 0, st, (const T*)qkv, (T*)cache, rows, Lq, D, cap, base);
+    return 0;
+  });
   return check_launch("kv_append");
 }
 
@@ -670,10 +685,11 @@ int modulate_rows(const void* x, const void* mod, void* out, long rows, int D, i
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "modulate_rows: D %% 4 != 0");
   const long total4 = rows * D / 4;
   const int blocks = (int)((total4 + 255) / 256 > 8192 ? 8192 : (total4 + 255) / 256);
-  if (dtype == NOVA_BF16)
-    hipLaunchKernelGGL(modulate_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)mod, (bf16_t*)out, total4, D);
-  else
-    hipLaunchKernelGGL(modulate_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)mod, (float*)out, total4, D);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(modulate_rows_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)mod, (T*)out, total4, D);
+    return 0;
+  });
   return check_launch("modulate_rows");
 }
 

@@ -24,9 +24,9 @@ namespace nova {
 
 constexpr int SK_R = 16, SK_C = 64;
 
-template <int K, int EPI, bool PRO, int RB>  // RB: 16-row blocks per workgroup (1, 2 or 4; the prologue form is RB = 1 only)
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
-                                                          bf16_t* __restrict__ C, int M, int N, const float* __restrict__ bias,
+template <typename T, int K, int EPI, bool PRO, int RB>  // T: bf16_t / f16_t; RB: 16-row blocks per workgroup (1, 2 or 4; the prologue form is RB = 1 only)
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                          T* __restrict__ C, int M, int N, const float* __restrict__ bias,
                                                           RowNormArgs pro) {
   constexpr int NS = K / 32;            // MFMA steps
   constexpr int LROW = K * 2 + 16;      // LDS row pitch: +16 B so the 16 rows of a fragment read start in different banks
@@ -40,11 +40,11 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
   const int m0 = tm * R, n0 = tn * SK_C + wid * 16;
 
   // ---- weights: lane (fr, fg) holds W[n0 + fr][32 s + 8 fg .. + 8] for every step s
-  bf8v wf[NS];
+  u4v wf[NS];
   {
-    const bf16_t* wp = W + (size_t)(n0 + fr) * K + 8 * fg;
+    const T* wp = W + (size_t)(n0 + fr) * K + 8 * fg;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) wf[s] = *reinterpret_cast<const bf8v*>(wp + 32 * s);
+    for (int s = 0; s < NS; ++s) wf[s] = *reinterpret_cast<const u4v*>(wp + 32 * s);
   }
   f4v acc[RB];
 #pragma unroll
@@ -53,19 +53,19 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
   // ---- activation rows -> LDS; wave w owns rows 4w .. 4w+3 (rows past M repeat row M-1 and are never stored); the
   // loads of all four rows are requested before the first row's reductions
   if (PRO) {
-    RowRegs<bf16_t, NIT, false, true> g[4];
+    RowRegs<T, NIT, false, true> g[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) row_norm_load<bf16_t, NIT, false, true>(pro, min(m0 + wid * 4 + i, M - 1), lane, g[i]);
+    for (int i = 0; i < 4; ++i) row_norm_load<T, NIT, false, true>(pro, min(m0 + wid * 4 + i, M - 1), lane, g[i]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      Chunk<bf16_t> y[NIT];
-      row_norm_finish<bf16_t, NIT, false, true>(pro, lane, g[i], y);
+      Chunk<T> y[NIT];
+      row_norm_finish<T, NIT, false, true>(pro, lane, g[i], y);
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int d = (it * 64 + lane) * 8;
         if (d < K) {
-          const u4v u = {pack_bf2(y[it].v[0][0], y[it].v[0][1]), pack_bf2(y[it].v[0][2], y[it].v[0][3]),
-                         pack_bf2(y[it].v[1][0], y[it].v[1][1]), pack_bf2(y[it].v[1][2], y[it].v[1][3])};
+          const u4v u = {Half16<T>::pack(y[it].v[0][0], y[it].v[0][1]), Half16<T>::pack(y[it].v[0][2], y[it].v[0][3]),
+                         Half16<T>::pack(y[it].v[1][0], y[it].v[1][1]), Half16<T>::pack(y[it].v[1][2], y[it].v[1][3])};
           *reinterpret_cast<u4v*>(smem + (wid * 4 + i) * LROW + d * 2) = u;
         }
       }
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
   for (int s = 0; s < NS; ++s)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const bf8v af = *reinterpret_cast<const bf8v*>(ap + rb * 16 * LROW + 64 * s);
-      acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af, acc[rb], 0, 0, 0);
+      const u4v af = *reinterpret_cast<const u4v*>(ap + rb * 16 * LROW + 64 * s);
+      acc[rb] = Half16<T>::mfma16(wf[s], af, acc[rb]);
     }
 
   // ---- epilogue: lane holds out[m0 + 16 rb + fr][n0 + 4 fg .. + 4]
@@ -115,31 +115,31 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const bf16_t* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
       }
-      const u2v o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+      const u2v o = {Half16<T>::pack(v[0], v[1]), Half16<T>::pack(v[2], v[3])};
       *reinterpret_cast<u2v*>(C + (size_t)m * N + n0 + 4 * fg) = o;
     }
   }
 }
 
-template <int K, bool PRO, int RB>
-static void launch_skinny(const bf16_t* A, const bf16_t* W, bf16_t* C, int M, int N, const float* bias, int act,
+template <typename T, int K, bool PRO, int RB>
+static void launch_skinny(const T* A, const T* W, T* C, int M, int N, const float* bias, int act,
                           const RowNormArgs& pro, hipStream_t st) {
   const dim3 grid((unsigned)(((M + SK_R * RB - 1) / (SK_R * RB)) * (N / SK_C))), block(256);
   switch (act) {
-    case 0: hipLaunchKernelGGL((skinny_gemm_kernel<K, 0, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
-    case 1: hipLaunchKernelGGL((skinny_gemm_kernel<K, 1, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
-    default: hipLaunchKernelGGL((skinny_gemm_kernel<K, 2, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+    case 0: hipLaunchKernelGGL((skinny_gemm_kernel<T, K, 0, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+    case 1: hipLaunchKernelGGL((skinny_gemm_kernel<T, K, 1, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
+    default: hipLaunchKernelGGL((skinny_gemm_kernel<T, K, 2, PRO, RB>), grid, block, 0, st, A, W, C, M, N, bias, pro); break;
   }
 }
 
-template <int K>
-static void launch_skinny_k(const bf16_t* a, const bf16_t* w, bf16_t* c, int M, int N, const float* bias, int act,
+template <typename T, int K>
+static void launch_skinny_k(const T* a, const T* w, T* c, int M, int N, const float* bias, int act,
                             const RowNormArgs* pro, int rb, hipStream_t st) {
   const RowNormArgs none{};
-  if (pro) launch_skinny<K, true, 1>(a, w, c, M, N, bias, act, *pro, st);
-  else if (rb == 1) launch_skinny<K, false, 1>(a, w, c, M, N, bias, act, none, st);
-  else if (rb == 2) launch_skinny<K, false, 2>(a, w, c, M, N, bias, act, none, st);
-  else launch_skinny<K, false, 4>(a, w, c, M, N, bias, act, none, st);
+  if (pro) launch_skinny<T, K, true, 1>(a, w, c, M, N, bias, act, *pro, st);
+  else if (rb == 1) launch_skinny<T, K, false, 1>(a, w, c, M, N, bias, act, none, st);
+  else if (rb == 2) launch_skinny<T, K, false, 2>(a, w, c, M, N, bias, act, none, st);
+  else launch_skinny<T, K, false, 4>(a, w, c, M, N, bias, act, none, st);
 }
 
 // Shapes this kernel is built for and worth using on. Every row tile re-reads the whole weight matrix and every column
@@ -169,21 +169,26 @@ bool skinny_gemm_fits(int M, int N, int K, bool modulate) { return skinny_row_bl
 // `pro` null: plain GEMM on A. Otherwise pro->in / mod / scale_off / shift_off / eps describe the AdaLN modulate whose
 // result is the A operand (pro->out, gamma, res, gate and gather are not used: the m1 form of diffusion_mlp.py:41-43).
 int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
-                const RowNormArgs* pro, hipStream_t st) {
+                const RowNormArgs* pro, int dtype, hipStream_t st) {
   if (M <= 0) return 0;
+  if (!dtype_is16(dtype)) return set_error(NOVA_ERR_ARG, "skinny_gemm: 16-bit storage types only");
   if ((K != 768 && K != 1024) || N % SK_C != 0) return set_error(NOVA_ERR_SHAPE, "skinny_gemm: need K in {768, 1024} and N %% 64 == 0 (got N=%d K=%d)", N, K);
   if (act < 0 || act > 2) return set_error(NOVA_ERR_ARG, "skinny_gemm: unknown activation %d", act);
   if (pro && (pro->D != K || pro->rows < M || !pro->in || !pro->mod || pro->scale_off < 0 || pro->shift_off < 0 || pro->gate_off >= 0 ||
               pro->gamma || pro->res || pro->gather || pro->mod_ld % 8 || pro->scale_off % 8 || pro->shift_off % 8))
     return set_error(NOVA_ERR_ARG, "skinny_gemm: the prologue is the scale/shift modulate of %d-wide rows only", K);
   ProfScope prof(PROF_GEMM_SMALL, 2.0 * M * N * K, st);
-  const bf16_t* a = static_cast<const bf16_t*>(A);
-  const bf16_t* w = static_cast<const bf16_t*>(W);
-  bf16_t* c = static_cast<bf16_t*>(out);
   int rb = pro ? 1 : skinny_row_blocks(M, N, K, false);
   if (rb == 0) rb = 1;  // forced onto a shape the traffic rule would not pick (nova_debug_force_gemm_tile(16))
-  if (K == 768) launch_skinny_k<768>(a, w, c, M, N, bias, act, pro, rb, st);
-  else launch_skinny_k<1024>(a, w, c, M, N, bias, act, pro, rb, st);
+  dispatch_half(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const T* a = static_cast<const T*>(A);
+    const T* w = static_cast<const T*>(W);
+    T* c = static_cast<T*>(out);
+    if (K == 768) launch_skinny_k<T, 768>(a, w, c, M, N, bias, act, pro, rb, st);
+    else launch_skinny_k<T, 1024>(a, w, c, M, N, bias, act, pro, rb, st);
+    return 0;
+  });
   return check_launch("skinny_gemm");
 }
 

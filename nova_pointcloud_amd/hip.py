@@ -11,7 +11,7 @@ import threading
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_GELU_ERF, ACT_SILU = 0, 1, 2
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libnova_hip.so")
@@ -91,7 +91,7 @@ SIGNATURES = {
     "nova_modulate_rows": [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p],
     "nova_attn_fwd_lse": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_long, c_long, c_void_p],
     "nova_attn_bwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_void_p],
-    "nova_row_norm_chain": [c_void_p] * 5 + [c_long, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "nova_row_norm_chain": [c_void_p] * 5 + [c_long, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "nova_adaln_fc1": [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_long]
     + [c_int] * 4 + [c_void_p],
     "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]
@@ -157,7 +157,9 @@ def dtype_code(dtype: torch.dtype) -> int:
         return F32
     if dtype == torch.bfloat16:
         return BF16
-    raise NovaHipError(f"libnova_hip supports float32 and bfloat16 activations, got {dtype}")
+    if dtype == torch.float16:
+        return F16
+    raise NovaHipError(f"libnova_hip supports float32, bfloat16 and float16 activations, got {dtype}")
 
 
 def stream_ptr() -> int:

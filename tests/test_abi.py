@@ -53,3 +53,20 @@ def test_missing_library_raises(monkeypatch):
     monkeypatch.setattr(H, "_LIB_PATH", "/nonexistent/libnova_hip.so")
     with pytest.raises(H.NovaHipError, match="no CPU fallback"):
         H.load(check_device=False)
+
+
+def test_dtype_codes_follow_the_header():
+    """NOVA_F32 / NOVA_BF16 / NOVA_F16 of include/nova_hip.h and the binding's torch dtype map (float16 is the default
+    precision of every caller of the reference: scripts/app_nova_t2i.py:36)."""
+    import re
+
+    import torch
+
+    from nova_pointcloud_amd import hip
+
+    enum = re.search(r"typedef enum \{([^}]*)\} nova_dtype;", open(HEADER).read()).group(1)
+    codes = {k.strip(): int(v) for k, v in (item.split("=") for item in enum.split(","))}
+    assert codes == {"NOVA_F32": 0, "NOVA_BF16": 1, "NOVA_F16": 2}
+    assert [hip.dtype_code(t) for t in (torch.float32, torch.bfloat16, torch.float16)] == [0, 1, 2]
+    with pytest.raises(hip.NovaHipError):
+        hip.dtype_code(torch.float64)

@@ -81,18 +81,27 @@ def test_two_rank_sharded_generation_equals_unsharded_run_of_the_same_seed(ragge
         assert (ref - gx).abs().max() <= 1e-4 * gx.abs().max()
 
 
-def test_bench_launch_contract_two_ranks_dry_run():
-    """The driver's N > 1 launch line, rehearsed on CPU (gloo): rendezvous, per-rank shard, gather, max-over-ranks timing."""
+@pytest.mark.parametrize("global_batch", [0, 3])
+def test_bench_launch_contract_two_ranks_dry_run(global_batch):
+    """The driver's N > 1 launch line, rehearsed on CPU (gloo): rendezvous, per-rank shard, gather, max-over-ranks timing; the
+    JSON line carries what the process group itself saw (`ranks_seen`), each rank's block of the global prompt list
+    (`shards`: [rank, lo, hi), incl. a ragged global batch of 3 over 2 ranks), and rank 0's check that the gathered rows are
+    the unsharded run's samples in prompt order."""
     import json
     import subprocess
 
-    port = 29700 + (os.getpid() % 200)
+    port = 29700 + (os.getpid() % 200) + global_batch
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--cpu-dry-run", "--workload", "d48w768_256pts_b1", "--ar-steps", "2", "--diffusion-steps", "2"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+           "--cpu-dry-run", "--workload", "d48w768_256pts_b1", "--ar-steps", "2", "--diffusion-steps", "2",
+           "--global-batch", str(global_batch)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout  # exactly one JSON line, from rank 0
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["points"] == [2, 256, 3]
+    G = global_batch or 2
+    assert rec["n_gpus"] == 2 and rec["points"] == [G, 256, 3]
+    assert rec["ranks_seen"] == [0, 1]
+    assert rec["shards"] == ([[0, 0, 1], [1, 1, 2]] if G == 2 else [[0, 0, 2], [1, 2, 3]])
+    assert rec["sharded_vs_unsharded_max_rel_diff"] < 1e-4

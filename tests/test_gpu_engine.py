@@ -24,6 +24,10 @@ from diffnext.schedulers import FlowMatchEulerDiscreteScheduler  # noqa: E402
 from test_mirror_cpu import VIDEO_VARIANTS, build_from_golden, video_call  # noqa: E402
 
 
+HALF = [torch.bfloat16, torch.float16]  # 16-bit storage modes; float16 is the default precision of the reference's callers
+HALF_BOUND = {torch.bfloat16: 1.0, torch.float16: 0.25}  # rms-relative bounds of the bf16 tests scale by this for float16 (3 more mantissa bits)
+
+
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return ((a - b).abs().max() / b.abs().max()).item()
@@ -58,11 +62,29 @@ def test_f32_pipeline_matches_reference_from_seed(gold, hip):
     assert err < 1e-4, f"f32 MFMA path should sit near f32 rounding, got {err:.3e}"
 
 
-def test_bf16_pipeline_close_to_reference_with_injected_order(gold, hip):
+@pytest.mark.parametrize("dtype", HALF)
+def test_16bit_pipeline_close_to_reference_with_injected_order(gold, hip, dtype):
     noises = gold.t["in/noises"]
-    pipe, x = run_pipe(gold, torch.bfloat16, pred_order=gold.t["out/order"][..., 0], noise_fn=lambda i: noises[i])
+    pipe, x = run_pipe(gold, dtype, pred_order=gold.t["out/order"][..., 0], noise_fn=lambda i: noises[i])
+    assert x.dtype == dtype
     err = rms_rel(x.float(), gold.t["out/x"])
-    assert err < 6e-2, err
+    assert err < 6e-2 * HALF_BOUND[dtype], err
+
+
+def test_builder_default_precision_runs_on_the_hip_path(gold, hip, tmp_path):
+    """What every caller of the reference does (scripts/app_nova_t2i.py:36,87-89: `build_pipeline(path, precision=float16)`
+    then `.to(device)`): a pipeline directory loaded with the builder's DEFAULT dtype generates on the GPU, in float16,
+    at float16 distance from the reference's f32 latents."""
+    from diffnext.pipelines.builder import build_pipeline
+
+    NOVAPipeline(transformer=build_from_golden(gold), scheduler=FlowMatchEulerDiscreteScheduler()).save_pretrained(str(tmp_path))
+    pipe = build_pipeline(str(tmp_path), NOVAPipeline).to("cuda")
+    assert pipe.transformer.dtype == torch.float16
+    m, noises = gold.meta, gold.t["in/noises"]
+    x = pipe(prompt_embeds=gold.prompt_embeds, num_inference_steps=m["K"], num_diffusion_steps=m["S"], guidance_scale=m["guidance"],
+             output_type="latent", disable_progress_bar=True, pred_order=gold.t["out/order"][..., 0], noise_fn=lambda i: noises[i]).frames
+    assert x.dtype == torch.float16 and x.is_cuda
+    assert rms_rel(x.float(), gold.t["out/x"]) < 6e-2 * HALF_BOUND[torch.float16]
 
 
 def test_video_and_image_encoder_modules_match_reference(gold, hip):
@@ -134,7 +156,7 @@ def _random_block_params(D, hidden, seed):
     return {"b." + k: v for k, v in p.items()}
 
 
-@pytest.mark.parametrize("dtype,bound", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("dtype,bound", [(torch.float32, 2e-4), (torch.bfloat16, 4e-2), (torch.float16, 6e-3)])
 def test_full_width_block_at_2560_tokens_matches_oracle(hip, dtype, bound):
     """One ViT block at the metric's size (D=1024, 16 heads, L=2560, RoPE over a 32x64 grid + 512-token prefix)."""
     from nova_pointcloud_amd import engine as E
@@ -185,8 +207,9 @@ def test_full_size_pipeline_properties(hip):
     assert (a[0] - a[1]).abs().max() > 1e-3
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("D,heads", [(768, 12), (1024, 16)])
-def test_small_batch_decoder_fusions_bitwise_and_against_oracle(hip, D, heads):
+def test_small_batch_decoder_fusions_bitwise_and_against_oracle(hip, D, heads, dtype):
     """The denoising loop at a few hundred rows (skinny.hip): modulate + fc1 + SiLU as one launch, small-M fc2, the last
     block's gated norm + the final modulate as one row kernel, all replayed as a hipGraph - on a D = 768 / 1024 stand-in
     with 3 decoder blocks, bf16. Must equal the 128-tile path (modulate as its own launch) bit for bit, with and without
@@ -212,8 +235,8 @@ def test_small_batch_decoder_fusions_bitwise_and_against_oracle(hip, D, heads):
     N = 80
     order = torch.stack([torch.randperm(N, generator=g) for _ in prompts])
     noises = torch.randn(5, len(prompts), 3, 8, 10, generator=g)
-    pipe = NOVAPipeline(transformer=model.to(torch.bfloat16).cuda(), scheduler=FlowMatchEulerDiscreteScheduler())
-    kw = dict(prompt_embeds=[p.cuda().bfloat16() for p in prompts], num_inference_steps=5, num_diffusion_steps=4, guidance_scale=4.0,
+    pipe = NOVAPipeline(transformer=model.to(dtype).cuda(), scheduler=FlowMatchEulerDiscreteScheduler())
+    kw = dict(prompt_embeds=[p.cuda().to(dtype) for p in prompts], num_inference_steps=5, num_diffusion_steps=4, guidance_scale=4.0,
               output_type="latent", disable_progress_bar=True, pred_order=order, noise_fn=lambda i: noises[i])
     runs = {}
     try:
@@ -239,7 +262,7 @@ def test_small_batch_decoder_fusions_bitwise_and_against_oracle(hip, D, heads):
     assert torch.equal(u_dist.argsort(dim=1)[..., 0], order)
     ref = O.generate(sd, cfg, prompt, O.cosine_schedule(N, 5), num_diffusion_steps=4, guidance_scale=4.0, u_dist=u_dist,
                      noises=list(noises))
-    assert rms_rel(runs["plain"].float(), ref) < 4e-2
+    assert rms_rel(runs["plain"].float(), ref) < 4e-2 * HALF_BOUND[dtype]
 
 
 def test_head_dim_96_model_matches_oracle(hip):
@@ -299,7 +322,7 @@ def test_f32_pipeline_ddpm_matches_oracle(gold, hip, pred_type):
     assert err < 1e-4, err
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_two_lanes_equal_one_lane(hip, dtype):
     """Half-batch lanes on two streams are a scheduling choice only: bit-identical points for lanes = 1, 2 (and 3)."""
     gold = Golden("tiny_rope")
@@ -461,12 +484,13 @@ def test_prefilled_first_frame_f32_matches_reference(vgold, hip):
     assert rel(x, ref) < 1e-4
 
 
-def test_multi_frame_bf16_and_lanes(vgold, hip):
+@pytest.mark.parametrize("dtype", HALF)
+def test_multi_frame_16bit_and_lanes(vgold, hip, dtype):
     """Throughput mode with the recorded order / per-step noise injected (rms-relative), and lanes = 2 == lanes = 1."""
     order, noises = vgold.t["out/order"][..., 0], vgold.t["in/noises"]
     kw = dict(pred_order=order, noise_fn=lambda i: noises[i], generator=None)
-    _, x = video_call(vgold, "cuda", torch.bfloat16, **kw)
-    assert rms_rel(x.float(), vgold.t["out/x"]) < 6e-2
+    _, x = video_call(vgold, "cuda", dtype, **kw)
+    assert rms_rel(x.float(), vgold.t["out/x"]) < 6e-2 * HALF_BOUND[dtype]
     if vgold.meta["B"] >= 2:
         a = video_call(vgold, "cuda", torch.float32, lanes=1, **kw)[1]
         b = video_call(vgold, "cuda", torch.float32, lanes=2, **kw)[1]
@@ -547,7 +571,7 @@ def test_fp8_gemm_mode_small_model(hip):
         NOVAPipeline(transformer=model.float(), scheduler=FlowMatchEulerDiscreteScheduler())(gemm_dtype="fp8", **kw)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_decoder_graph_replay_equals_direct_launches(gold, hip, dtype):
     """nova_decoder_denoise captures its launch sequence per argument set and replays it as a hipGraph: the first call
     of a pipeline captures (one graph per AR step and lane), a second call with the same schedule replays every one of
@@ -580,7 +604,7 @@ def test_decoder_graph_replay_equals_direct_launches(gold, hip, dtype):
     assert torch.equal(third, direct3) and not torch.equal(third, direct)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_adaln_projection_hoisted_over_steps_equals_per_step(gold, hip, dtype):
     """nova_decoder_denoise mod_steps = steps (one AdaLN GEMM for all diffusion steps) against mod_steps = 1: identical
     points, with guidance truncation switching the pass count mid-loop as well."""

@@ -2,7 +2,8 @@
 
 Every call goes through the C ABI (ctypes). Tolerances: f32 mode runs on exact-f32 MFMA so only
 summation order differs (1e-5 relative to the row scale); bf16 mode is bounded by bf16 storage
-rounding of inputs/outputs (2^-8 relative) with f32 accumulation.
+rounding of inputs/outputs (2^-8 relative) with f32 accumulation, f16 mode (the reference callers' default precision,
+scripts/app_nova_t2i.py:36) likewise by 2^-11.
 """
 import math
 
@@ -12,11 +13,12 @@ import torch
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
-DTYPES = [torch.float32, torch.bfloat16]
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]
+HALF = [torch.bfloat16, torch.float16]  # the two 16-bit storage modes run the same kernels on the bf16 / f16 MFMA forms
 
 
 def tol(dtype):
-    return 2e-5 if dtype == torch.float32 else 1.6e-2
+    return {torch.float32: 2e-5, torch.bfloat16: 1.6e-2, torch.float16: 2e-3}[dtype]
 
 
 def relerr(got, ref):
@@ -169,12 +171,13 @@ def test_attention_spiky_rows(hip, dtype, hd):
     assert relerr(out, ref) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("S,heads,L", [(1, 1, 64), (2, 3, 200), (1, 2, 333), (3, 1, 31), (1, 4, 769), (2, 2, 2560)])
-def test_attention_structures_bf16(hip, variant, S, heads, L):
+def test_attention_structures_16bit(hip, dtype, variant, S, heads, L):
     """The three bf16 / head_dim 64 structures (32x32x16; 16x16x32 at 32 and at 64 query rows per wave) against SDPA in f32,
     incl. ragged last tiles and the forced late-max rescale (cdna_hip_programming rule 26)."""
-    hd, dtype = 64, torch.bfloat16
+    hd = 64
     D = heads * hd
     qkv = rnd(S * L, 3 * D, dtype=dtype, seed=7)
     if L >= 200:  # spike: key L-3 aligned with query 5, key 70 with query 77 of head 0 -> the running max jumps late in the stream
@@ -191,7 +194,7 @@ def test_attention_structures_bf16(hip, variant, S, heads, L):
     assert relerr(out, ref) < tol(dtype)
     # row-wise: every query row within bf16 rounding of the reference row (a wrong lane map hides in a global norm)
     row_err = (out.float() - ref).abs().amax(1) / ref.abs().amax(1).clamp_min(1e-6)
-    assert row_err.max().item() < 4e-2, (variant, row_err.argmax().item(), row_err.max().item())
+    assert row_err.max().item() < 2.5 * tol(dtype), (variant, row_err.argmax().item(), row_err.max().item())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -322,10 +325,10 @@ def test_gemm_256_tile_bitwise_equals_128_tile(hip, force_tile, form, dtype, M, 
 
 @pytest.mark.parametrize("M,N,K,act", [(1, 768, 768, 0), (16, 768, 768, 2), (200, 768, 768, 2), (257, 3072, 768, 1), (999, 1024, 1024, 2),
                                         (130, 4096, 1024, 1), (64, 64, 1024, 0), (1500, 1024, 1024, 2), (3000, 768, 768, 0)])
-def test_small_m_gemm_bitwise_equals_tile_kernels(hip, force_tile, M, N, K, act):
+@pytest.mark.parametrize("dtype", HALF)
+def test_small_m_gemm_bitwise_equals_tile_kernels(hip, force_tile, dtype, M, N, K, act):
     """skinny.hip (whole-K workgroups, weights global -> registers) against the 128-tile kernel, bit for bit: the kernel
     picked by the row count must never show in the result (batch / lane splits of the engine rely on it)."""
-    dtype = torch.bfloat16
     a, w = rnd(M, K, dtype=dtype, seed=51), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=52)
     bias = rnd(N, seed=53)
     force_tile(16)
@@ -352,11 +355,12 @@ def test_small_m_gemm_rejects_other_shapes(hip, force_tile):
         hip.gemm_bias_act(a, w, None, 0)
 
 
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("D", [128, 768, 1024, 1536])
-def test_row_norm_chain_equals_two_row_norms(hip, D):
+def test_row_norm_chain_equals_two_row_norms(hip, dtype, D):
     """Last block's gated norm + residual and the final layer's modulate as one row pass (nova_row_norm_chain) against
     nova_row_norm twice: identical bits for h and for the stored x_new."""
-    dtype, rows = torch.bfloat16, 203
+    rows = 203
     g, x = rnd(rows, D, dtype=dtype, seed=71), rnd(rows, D, dtype=dtype, seed=72)
     gamma, beta = rnd(D, seed=73) + 1, rnd(D, seed=74)
     mod = rnd(rows, 5 * D, dtype=dtype, scale=0.5, seed=75)
@@ -364,19 +368,19 @@ def test_row_norm_chain_equals_two_row_norms(hip, D):
     h_two = hip.row_norm(x_two, mod=mod, scale_off=D, shift_off=2 * D, eps=1e-6)
     x_new, h = torch.empty_like(x), torch.empty_like(x)
     hip.call("nova_row_norm_chain", hip.ptr(g), hip.ptr(x), hip.ptr(gamma, torch.float32), hip.ptr(beta, torch.float32), hip.ptr(mod),
-             mod.shape[1], 4 * D, D, 2 * D, 1e-5, 1e-6, hip.ptr(x_new), hip.ptr(h), rows, D, hip.stream_ptr())
+             mod.shape[1], 4 * D, D, 2 * D, 1e-5, 1e-6, hip.ptr(x_new), hip.ptr(h), rows, D, hip.dtype_code(dtype), hip.stream_ptr())
     assert torch.equal(x_new, x_two) and torch.equal(h, h_two)
     h2 = torch.empty_like(x)
     hip.call("nova_row_norm_chain", hip.ptr(g), hip.ptr(x), hip.ptr(gamma, torch.float32), hip.ptr(beta, torch.float32), hip.ptr(mod),
-             mod.shape[1], 4 * D, D, 2 * D, 1e-5, 1e-6, None, hip.ptr(h2), rows, D, hip.stream_ptr())
+             mod.shape[1], 4 * D, D, 2 * D, 1e-5, 1e-6, None, hip.ptr(h2), rows, D, hip.dtype_code(dtype), hip.stream_ptr())
     assert torch.equal(h2, h_two)
 
 
 @pytest.mark.parametrize("rows,D,N", [(1, 768, 768), (37, 768, 768), (256, 768, 768), (300, 1024, 1024), (77, 1024, 2048)])
-def test_adaln_fc1_fused_equals_two_launches(hip, force_tile, rows, D, N):
+@pytest.mark.parametrize("dtype", HALF)
+def test_adaln_fc1_fused_equals_two_launches(hip, force_tile, dtype, rows, D, N):
     """modulate -> fc1 -> SiLU (diffusion_mlp.py:41-47) as ONE launch (LN prologue inside the small-M GEMM) against
     nova_row_norm followed by the GEMM: identical bits, and both close to fp32 math."""
-    dtype = torch.bfloat16
     x = rnd(rows, D, dtype=dtype, seed=61)
     mod = rnd(rows, 5 * D, dtype=dtype, scale=0.5, seed=62)
     w, bias = rnd(N, D, dtype=dtype, scale=D ** -0.5, seed=63), rnd(N, seed=64)

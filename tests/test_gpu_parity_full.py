@@ -45,7 +45,11 @@ ARCHS = {
     "d48w1024_2048pts": (1024, 16, 32, 64, 2, 3, 2, 4e-2),  # configs[2] / [3]: the headline architecture
     "d48w768_1024pts": (768, 12, 32, 32, 2, 3, 2, 4e-2),    # configs[1]
     "d48w1536_2048pts": (1536, 16, 32, 64, 1, 2, 2, 4e-2),  # configs[4] architecture (head_dim 96) in f32 / bf16
+    # depth in SCHEDULE (round 3): the AR loop feeds its own output back K times and the Euler loop S times
+    "config0_d48w768_256pts_K4S4": (768, 12, 16, 16, 1, 4, 4, 4e-2),     # BASELINE configs[0] IN FULL (256 points, 4 x 4 steps, batch 1)
+    "sched_d48w768_1024pts_K16S8": (768, 12, 32, 32, 1, 16, 8, 8e-2),    # 16 AR x 8 diffusion steps: error growth over the schedule
 }
+SCHEDULE_CASES = ("config0_d48w768_256pts_K4S4", "sched_d48w768_1024pts_K16S8")
 
 
 @pytest.fixture(scope="module", params=sorted(ARCHS))
@@ -101,21 +105,25 @@ def test_f32_from_seed_matches_oracle_at_full_depth(case, hip):
     assert err < 2e-4, f"f32 MFMA path measured 2-4e-5 at full depth, got {err:.3e}"
 
 
-def test_bf16_injected_draws_close_to_oracle_at_full_depth(case, hip):
-    """Throughput mode (bf16 storage, f32 accumulate): weights rounded to bf16 on the GPU side only - the error
-    reported is the whole bf16 effect against the f32 reference, as north_star's 'bf16 vs reference CPU path'."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_16bit_injected_draws_close_to_oracle_at_full_depth(case, hip, dtype):
+    """Throughput modes (bf16 / f16 storage, f32 accumulate): weights rounded to the storage type on the GPU side only - the
+    error reported is the whole 16-bit effect against the f32 reference, as north_star's 'bf16 vs reference CPU path';
+    float16 (3 more mantissa bits, the reference callers' default: scripts/app_nova_t2i.py:36) is held to a quarter of it."""
     order, noises = case["order"], case["noises"]
-    x = run(case, torch.bfloat16, pred_order=order, noise_fn=lambda i: noises[i])
+    x = run(case, dtype, pred_order=order, noise_fn=lambda i: noises[i])
     assert torch.isfinite(x).all()
     err, mx = rms_rel(x, case["ref"]), rel(x, case["ref"])
-    print(f"\n[parity-full] {case['name']} bf16 injected: rms rel {err:.3e}, max rel {mx:.3e}")
-    assert err < case["bf16_bound"], err
+    print(f"\n[parity-full] {case['name']} {str(dtype).split('.')[-1]} injected: rms rel {err:.3e}, max rel {mx:.3e}")
+    assert err < case["bf16_bound"] * (1.0 if dtype == torch.bfloat16 else 0.25), err
 
 
 def test_fp8_gemm_mode_against_bf16_and_oracle_at_full_depth(case, hip):
     """BASELINE configs[4]: the encoder's QKV / fc1 / fc2 GEMMs on the block-scaled fp8 MFMA. The
     reference has no fp8 path, so the result is compared with this build's bf16 output under the same injected order and
     noise (rms-relative, reported), and with the f32 oracle for scale."""
+    if case["name"] in SCHEDULE_CASES:
+        pytest.skip("fp8 mode is measured at the three architecture cases")
     order, noises = case["order"], case["noises"]
     kw = dict(pred_order=order, noise_fn=lambda i: noises[i])
     x16 = run(case, torch.bfloat16, **kw)
@@ -123,4 +131,4 @@ def test_fp8_gemm_mode_against_bf16_and_oracle_at_full_depth(case, hip):
     assert torch.isfinite(x8).all()
     e_bf16, e_ref = rms_rel(x8, x16), rms_rel(x8, case["ref"])
     print(f"\n[parity-full] {case['name']} fp8 GEMMs: rms rel vs bf16 {e_bf16:.3e}, vs f32 oracle {e_ref:.3e}")
-    assert e_bf16 < 0.25, e_bf16
+    assert e_bf16 < 0.12, e_bf16  # measured 7.0-7.6e-2

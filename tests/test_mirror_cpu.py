@@ -305,3 +305,35 @@ def test_training_attention_dispatch_rules():
     assert not A.attention_supported(FakeCuda((2, 3, 16, 64), torch.float32))
     assert not A.attention_supported(FakeCuda((2, 3, 16, 128), torch.bfloat16))
     assert not A.attention_supported(FakeCuda((6, 16, 64), torch.bfloat16))
+
+
+def test_config0_in_full_on_the_cpu_module_path_matches_oracle():
+    """BASELINE configs[0] IN FULL - NOVA-d48w768 (16 + 32 ViT blocks, 6 diffusion-MLP blocks, random init), 256 points,
+    4 AR x 4 diffusion steps, batch 1 - through `NOVAPipeline.__call__` on the drop-in's CPU module path (the reference's
+    own CPU/PyTorch semantics of the module API), against the oracle on the same weights, prompt and host generator seed.
+    The same oracle run is what the HIP path is held to on the GPU box (tests/test_gpu_parity_full.py, case
+    config0_d48w768_256pts_K4S4)."""
+    import bench
+    from oracle import nova_oracle as O
+
+    H = W = 16
+    K = S = 4
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(threads, min(bench.host_cores(), 8)))
+    try:
+        pipe = bench.build_pipeline(768, 12, H, W, torch.float32, torch.device("cpu"))
+        sd = {k: v.detach().clone() for k, v in pipe.transformer.state_dict().items()}
+        prompts = bench.synthetic_prompts(1, "cpu", torch.float32, seed=4321)
+        sched = [int(v) for v in O.cosine_schedule(H * W, K) if v > 0]
+        assert sched == [19, 56, 83, 98]  # SURVEY appendix A.1
+        cfg = O.make_config(3, (H, W), 1, 768, 12, 16, 32, 6, 256, rotary=True)
+        prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 256)
+        with torch.no_grad():
+            ref = O.generate(sd, cfg, prompt, sched, num_diffusion_steps=S, guidance_scale=5.0, generator=torch.Generator().manual_seed(29))
+            out = pipe(prompt_embeds=prompts, num_inference_steps=K, num_diffusion_steps=S, guidance_scale=5, output_type="latent",
+                       disable_progress_bar=True, generator=torch.Generator().manual_seed(29)).frames
+    finally:
+        torch.set_num_threads(threads)
+    assert tuple(out.shape) == (1, 3, 1, H, W) and torch.isfinite(out).all()
+    err = ((out.double() - ref.double()).abs().max() / ref.double().abs().max()).item()
+    assert err < 1e-4, err  # two f32 CPU evaluations of the same arithmetic: summation order only
