@@ -128,7 +128,7 @@ def cpu_baseline(pipe, width, heads, H, W, threads, with_config0=False):
     return rec
 
 
-PMC_KERNEL = {"attention": "attn_bf16<64,false>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
+PMC_KERNEL = {"attention": "attn_bf16_m16<bf16,2,false,true>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
               "qkv_gemm_rope": "gemm256p_kernel<bf16,3>"}
 
 

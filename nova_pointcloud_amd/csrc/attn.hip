@@ -412,8 +412,8 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (dtype_is16(dtype)) {
     const float cl = q_prescaled ? 1.0f : c;
     const int rev = walk_is_reverse() ? 1 : 0;
-    if (hd == 64 && attn_variant() != 0)
-      return attn_fwd_m16(q, k, v, o, S, heads, Lq, Lk, q_rs, kv_rs, o_rs, cl, dtype, st, kv_ss, lse, (attn_variant() & 1) && attn_variant() != 5 ? 32 : 64,
+    if (attn_variant() != 0)
+      return attn_fwd_m16(q, k, v, o, S, heads, Lq, Lk, hd, q_rs, kv_rs, o_rs, cl, dtype, st, kv_ss, lse, (attn_variant() & 1) && attn_variant() != 5 ? 32 : 64,
                           attn_variant() >= 3, attn_variant() == 5);
     dispatch_half(dtype, [&](auto tag) {
       using E = decltype(tag);

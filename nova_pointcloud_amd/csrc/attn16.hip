@@ -57,13 +57,17 @@ __device__ __forceinline__ float sum_over_g(float x) {
 }
 }  // namespace
 
-template <typename E, int NQB, bool LSE, bool SUMM>  // E: bf16_t / f16_t (same loads, LDS images and stores; MFMA form and pair packing differ)
-__global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const E* __restrict__ q, const E* __restrict__ k,
+// HD = 96 (d48w1536): a 64-wide image plus a 32-wide image (64-byte rows) per K / V tile, as attn.hip, so every LDS-DMA piece
+// stays row aligned; their swizzles: K32 chunk ^ s((row >> 2) & 3), s = (0, 2, 3, 1); V32 chunk ^ (((row >> 2) & 1) << 1).
+template <typename E, int HD, int NQB, bool LSE, bool SUMM>  // E: bf16_t / f16_t (same loads, LDS images and stores; MFMA form and pair packing differ)
+__global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16_m16(const E* __restrict__ q, const E* __restrict__ k,
                                                                          const E* __restrict__ v, E* __restrict__ o,
                                                                          int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
                                                                          int heads, int nq, int rev, long kv_ss, float* __restrict__ lse) {
-  constexpr int HD = 64, NDS = HD / 32, NDVB = HD / 16, RW = 16 * NQB;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * B_T];  // [buffer][K | V]
+  constexpr int NDS = HD / 32, NDVB = HD / 16, RW = 16 * NQB;
+  constexpr int B_T32 = B_KV * 64;                                  // 32-wide image (HD = 96): 4 KiB
+  constexpr int BUF = 2 * B_T + (HD == 96 ? 2 * B_T32 : 0);         // [K64 | V64 | K32 | V32]
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
@@ -101,8 +105,12 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const E* 
   const uint32_t ck0 = (uint32_t)((scp ^ ((srow0 >> 1) & 7)) << 4), ck1 = (uint32_t)((scp ^ ((srow1 >> 1) & 7)) << 4);
   const uint32_t cv0 = (uint32_t)((scp ^ (((srow0 >> 1) & 3) << 1)) << 4), cv1 = (uint32_t)((scp ^ (((srow1 >> 1) & 3) << 1)) << 4);
   const uint32_t ko0 = srow0 * rowB + ck0, ko1 = srow1 * rowB + ck1, vo0 = srow0 * rowB + cv0, vo1 = srow1 * rowB + cv1;
+  // 32-wide images: wave w moves piece w (16 rows x 64 B) of each; source columns 64 .. 95 = byte 128 + 16 * chunk
+  const int srow32 = wid * 16 + (lane >> 2), scp32 = lane & 3;
+  const uint32_t ck32 = 128u + (uint32_t)((scp32 ^ ((0x78 >> (2 * ((srow32 >> 2) & 3))) & 3)) << 4);
+  const uint32_t cv32 = 128u + (uint32_t)((scp32 ^ (((srow32 >> 2) & 1) << 1)) << 4);
   auto stage = [&](int buf, int kt) {
-    char* lk = smem + buf * 2 * B_T;
+    char* lk = smem + buf * BUF;
     char* lv = lk + B_T;
     const char* kbase = reinterpret_cast<const char*>(kb_) + (size_t)kt * B_KV * rowB;  // wave-uniform
     const char* vbase = reinterpret_cast<const char*>(vb_) + (size_t)kt * B_KV * rowB;
@@ -112,12 +120,21 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const E* 
       glds16(vbase, vo0, lv + wid * 2048);
       glds16(kbase, ko1, lk + wid * 2048 + 1024);
       glds16(vbase, vo1, lv + wid * 2048 + 1024);
+      if constexpr (HD == 96) {
+        glds16(kbase, srow32 * rowB + ck32, lk + 2 * B_T + wid * 1024);
+        glds16(vbase, srow32 * rowB + cv32, lk + 2 * B_T + B_T32 + wid * 1024);
+      }
     } else {  // ragged tile: rows past Lk re-read the last valid row (their scores are masked to -inf)
       const uint32_t r0 = (uint32_t)min(srow0, lim) * rowB, r1 = (uint32_t)min(srow1, lim) * rowB;
       glds16(kbase, r0 + ck0, lk + wid * 2048);
       glds16(vbase, r0 + cv0, lv + wid * 2048);
       glds16(kbase, r1 + ck1, lk + wid * 2048 + 1024);
       glds16(vbase, r1 + cv1, lv + wid * 2048 + 1024);
+      if constexpr (HD == 96) {
+        const uint32_t r32 = (uint32_t)min(srow32, lim) * rowB;
+        glds16(kbase, r32 + ck32, lk + 2 * B_T + wid * 1024);
+        glds16(vbase, r32 + cv32, lk + 2 * B_T + B_T32 + wid * 1024);
+      }
     }
   };
 
@@ -141,9 +158,12 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const E* 
   const int t_q = (lane & 15) >> 2, t_p = lane & 3;
   const uint32_t vrow = (uint32_t)(4 * g + t_q);                                   // + 32 kp (+ 16 for the high half): swizzle unchanged
   const uint32_t vx = ((vrow >> 1) & 3u) << 1;
-  uint32_t voff[NDVB];
+  uint32_t voff[NDVB];  // dvb < 4: inside the 64-wide V image; dvb 4, 5: inside the 32-wide one (64-byte rows)
 #pragma unroll
-  for (int dvb = 0; dvb < NDVB; ++dvb) voff[dvb] = vrow * 128u + ((((uint32_t)(2 * dvb + (t_p >> 1))) ^ vx) << 4) + 8u * (t_p & 1);
+  for (int dvb = 0; dvb < NDVB; ++dvb)
+    voff[dvb] = dvb < 4 ? vrow * 128u + ((((uint32_t)(2 * dvb + (t_p >> 1))) ^ vx) << 4) + 8u * (t_p & 1)
+                        : vrow * 64u + ((((uint32_t)(2 * (dvb - 4) + (t_p >> 1))) ^ (((vrow >> 2) & 1u) << 1)) << 4) + 8u * (t_p & 1);
+  const uint32_t koff2 = (uint32_t)i * 64u + (((uint32_t)g ^ (uint32_t)((0x78 >> (2 * ((i >> 2) & 3))) & 3)) << 4);  // d-step 2: the 32-wide K image
 
   const int nkt = (Lk + B_KV - 1) / B_KV;
   // Tile order: the (possibly ragged) LAST tile goes first, as a peeled step (softmax does not care about key order), so the
@@ -151,15 +171,18 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const E* 
   // max chains under the score MFMAs: step 0 <-> tile nkt - 1, step j >= 1 <-> tile j - 1; K/V of step j in buffer j & 1.
   auto step = [&](auto first, int buf) {
     constexpr bool FIRST = decltype(first)::value;
-    const char* tk = smem + buf * 2 * B_T;
+    const char* tk = smem + buf * BUF;
     const char* tv = tk + B_T;
+    const char* tk32 = tk + 2 * B_T;
+    const char* tv32 = tk32 + B_T32;
     // ---- S^T[key][q] - m: 4 key blocks x NQB query blocks, every K fragment feeds NQB MFMAs
     f4v st[NQB][4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int ds = 0; ds < NDS; ++ds) {
-        const u4v kf = *reinterpret_cast<const u4v*>(tk + kb * 2048 + (ds == 0 ? koff0 : koff1));
+        const u4v kf = ds < 2 ? *reinterpret_cast<const u4v*>(tk + kb * 2048 + (ds == 0 ? koff0 : koff1))
+                              : *reinterpret_cast<const u4v*>(tk32 + kb * 1024 + koff2);
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
           st[qb][kb] = Half16<E>::mfma16(kf, qf[qb][ds], ds == 0 ? negm[qb] : st[qb][kb]);
@@ -230,9 +253,9 @@ __global__ __launch_bounds__(256, NQB == 2 ? 3 : 2) void attn_bf16_m16(const E* 
     for (int kp = 0; kp < 2; ++kp) {
 #pragma unroll
       for (int dvb = 0; dvb < NDVB; ++dvb) {
-        const char* a0 = tv + kp * 4096 + voff[dvb];
+        const char* a0 = dvb < 4 ? tv + kp * 4096 + voff[dvb] : tv32 + kp * 2048 + voff[dvb];
         const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
-        const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(a0 + 2048));
+        const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(a0 + (dvb < 4 ? 2048 : 1024)));
         const u4v vf = __builtin_bit_cast(u4v, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) ot[qb][dvb] = Half16<E>::mfma16(vf, pb[qb][kp], ot[qb][dvb]);
@@ -527,10 +550,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const E* __restrict__ q
   }
 }
 
-// rows_per_wave 32 or 64; head_dim 64; dtype NOVA_BF16 or NOVA_F16 (attn_fwd in attn.hip checks shapes and strides before it dispatches here)
-int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, long q_rs, long kv_rs,
+// rows_per_wave 32 or 64 (head_dim 64; head_dim 96 runs the 32-row form with MFMA row sums whatever is asked); dtype NOVA_BF16 or NOVA_F16 (attn_fwd in attn.hip checks shapes and strides before it dispatches here)
+int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd, long q_rs, long kv_rs,
                  long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined) {
-  const int rw = rows_per_wave == 64 ? 64 : 32;
+  const int rw = (rows_per_wave == 64 && hd == 64) ? 64 : 32;
   const int nq = (Lq + 4 * rw - 1) / (4 * rw);
   if ((long)nq * heads * S > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
   dim3 block(256), grid((unsigned)((long)nq * heads * S));
@@ -541,10 +564,13 @@ int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, in
     E* oo = (E*)o;
 #define NOVA_A16(NQB_, SUMM_)                                                                                                       \
   do {                                                                                                                             \
-    if (lse) hipLaunchKernelGGL((attn_bf16_m16<E, NQB_, true, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse); \
-    else hipLaunchKernelGGL((attn_bf16_m16<E, NQB_, false, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);    \
+    if (lse) hipLaunchKernelGGL((attn_bf16_m16<E, 64, NQB_, true, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse); \
+    else hipLaunchKernelGGL((attn_bf16_m16<E, 64, NQB_, false, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);    \
   } while (0)
-    if (pipelined) {
+    if (hd == 96) {  // built in the shipped form only: 32 rows per wave, row sums on the matrix pipe
+      if (lse) hipLaunchKernelGGL((attn_bf16_m16<E, 96, 2, true, true>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+      else hipLaunchKernelGGL((attn_bf16_m16<E, 96, 2, false, true>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
+    } else if (pipelined) {
       if (lse) hipLaunchKernelGGL((attn_bf16_m16p<E, true>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
       else hipLaunchKernelGGL((attn_bf16_m16p<E, false>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);
     } else if (rw == 32 && !sum_on_mfma) NOVA_A16(2, false);

@@ -618,7 +618,7 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
   for (int i = 0; i < steps; ++i) key_put(key, sched[i]);
   const void* ptrs[] = {zc, temb, x, ws_a, ws_u, ws_h, ws_f, ws_g, ws_mod, (const void*)st};
   key_put(key, ptrs);
-  const int ints[] = {steps, S, B, n, P, D, mod_steps, dtype, walk_is_reverse() ? 1 : 0, gemm_forced_tile()};
+  const int ints[] = {steps, S, B, n, P, D, mod_steps, dtype, walk_is_reverse() ? 1 : 0, gemm_forced_tile(), skinny_forced_row_blocks()};
   key_put(key, ints);
   auto it = g_dec_graphs.execs.find(key);
   if (it == g_dec_graphs.execs.end()) {
@@ -636,11 +636,14 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
       if (graph) (void)hipGraphDestroy(graph);
       return rc;
     }
-    NOVA_REQUIRE(ec == hipSuccess && graph, NOVA_ERR_LAUNCH, "decoder_denoise: stream capture failed: %s", hipGetErrorString(ec));
     hipGraphExec_t exec = nullptr;
-    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    NOVA_REQUIRE(ei == hipSuccess && exec, NOVA_ERR_LAUNCH, "decoder_denoise: hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+    const hipError_t ei = (ec == hipSuccess && graph) ? hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) : ec;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) {  // nothing has executed yet (the launches above were only recorded): run them directly
+      (void)hipGetLastError();
+      return decoder_denoise_launches(dec, zc, temb, x, sched, noise, renorm, echo_energy, steps, S, B, n, P, D, ws_a, ws_u, ws_h, ws_f,
+                                      ws_g, ws_mod, ws_v, mod_steps, dtype, st);
+    }
     it = g_dec_graphs.execs.emplace(std::move(key), exec).first;
     ++g_dec_graphs.captures;
   } else {

@@ -55,7 +55,7 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
              long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st,
              bool q_prescaled = false, long kv_seq_stride = 0, float* lse = nullptr);
 // attn16.hip: the same attention on the 16x16x32 MFMA shape (bf16, head_dim 64), 32 or 64 query rows per wave
-int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, long q_rs, long kv_rs,
+int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd, long q_rs, long kv_rs,
                  long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined = false);
 constexpr int NOVA_ATTN_DEFAULT_VARIANT = 3;  // 16x16x32, 32 rows per wave, row sums on the matrix pipe: +8..11 % over variant 0 at every L measured (profiles/r03_attn_variants.txt)
 int attn_set_variant(int v);  // -1 default, 0 .. 5 (attn.hip); -1 returned for other values
@@ -89,6 +89,7 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
 
 // ---- skinny.hip: small-M GEMM (bf16 / f16, K in {768, 1024}), bit-identical to the tile kernels; optional AdaLN-modulate prologue
 bool skinny_gemm_fits(int M, int N, int K, bool modulate);
+int skinny_forced_row_blocks();  // the calling thread's current setting (part of the decoder graph key)
 void skinny_force_row_blocks(int rb);  // calling thread: 1 / 2 / 4 = rows per workgroup 16 / 32 / 64 for plain launches, 0 = by rule
 int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                 const RowNormArgs* pro, int dtype, hipStream_t st);

@@ -152,6 +152,7 @@ static void launch_skinny_k(const T* a, const T* w, T* c, int M, int N, const fl
 // skinny_row_blocks returns 1, 2, 4 (x 16 rows) or 0 = use the tile kernels.
 static thread_local int g_skinny_rb = 0;  // tools / tests: force a row-block count (0 = by the rule above)
 void skinny_force_row_blocks(int rb) { g_skinny_rb = rb; }
+int skinny_forced_row_blocks() { return g_skinny_rb; }
 
 int skinny_row_blocks(int M, int N, int K, bool modulate) {
   if (M <= 0 || (K != 768 && K != 1024) || N % SK_C != 0) return 0;

@@ -113,7 +113,12 @@ except ImportError:
             if not os.path.isdir(directory):
                 raise OSError(f"{directory} is not a local directory (no network access from this build)")
             model = cls.from_config(cls.load_config(directory))
-            model.load_state_dict(load_file(os.path.join(directory, cls.weights_name)))
+            path = os.path.join(directory, cls.weights_name)
+            legacy = os.path.join(directory, "diffusion_pytorch_model.bin")  # what the reference's trainer writes (safe_serialization=False)
+            if not os.path.exists(path) and os.path.exists(legacy):
+                model.load_state_dict(torch.load(legacy, map_location="cpu", weights_only=True))
+            else:
+                model.load_state_dict(load_file(path))
             return model.to(torch_dtype).eval() if torch_dtype is not None else model.eval()
 
     class SchedulerMixin(object):

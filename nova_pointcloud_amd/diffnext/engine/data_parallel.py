@@ -37,19 +37,25 @@ class GradientReducer(object):
 
     @torch.no_grad()
     def sync_gradients(self):
-        """Average the accumulated gradients over the ranks, bucket by bucket (parameters without a gradient count as 0)."""
+        """Average the accumulated gradients over the ranks, bucket by bucket. A parameter without a gradient contributes zeros
+        to the exchange (the payload must have one shape on every rank) and keeps `grad = None` afterwards unless some rank
+        did produce one - so parameters off the current path (frame mixer, frame patch-embed at T = 1) get no weight decay or
+        moment updates, exactly as in a single-process run and in the reference."""
         if not self.active:
             return
         for bucket in self.buckets:
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+            has = torch.tensor([0.0 if p.grad is None else 1.0 for p in bucket], dtype=torch.float32, device=bucket[0].device)
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket] + [has.to(bucket[0].dtype)])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.div_(self.world)
+            anyone = flat[-len(bucket):].float() > 0
+            flat = flat[:-len(bucket)].div_(self.world)
             off = 0
-            for p in bucket:
+            for p, used in zip(bucket, anyone.tolist()):
                 g = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
                 if p.grad is None:
-                    p.grad = g.clone()
+                    if used:
+                        p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
 

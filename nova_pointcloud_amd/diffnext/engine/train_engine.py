@@ -80,6 +80,20 @@ class Trainer(object):
         self.logger = logger or logging.getLogger("diffnext.train")
         self.model = configure_model(model, config, noise_scheduler)
         self.ema = engine_utils.ModelEMA(self.model, **config["ema"].get("params", {})) if "ema" in config else None
+        exp = config.get("experiment", {})
+        if self.ema is not None and exp.get("resume_iter", 0) > 0 and exp.get("resume_from_checkpoint"):
+            # a resumed run continues the averaged weights it had written beside the checkpoint (the reference reloads
+            # ema_checkpoints/<ckpt>/<model.name> when resume_iter > 0: engine/train_engine.py:52-56), not a fresh copy of the raw ones
+            ema_dir = os.path.join(exp["resume_from_checkpoint"].replace("checkpoints", "ema_checkpoints"),
+                                   config.get("model", {}).get("name", "transformer"))
+            if os.path.isdir(ema_dir):
+                saved = type(self.ema.model).from_pretrained(ema_dir).state_dict()
+                with torch.no_grad():
+                    for k, v in self.ema.model.state_dict().items():
+                        v.copy_(saved[k].to(v.dtype))
+                self.logger.info("Resumed EMA weights from: %s", ema_dir)
+            else:
+                self.logger.warning("EMA configured but %s does not exist: averaging restarts from the resumed weights", ema_dir)
         groups = engine_utils.get_param_groups(self.model)
         opt = config.get("optimizer", {"target": "AdamW", "params": {"lr": 1e-4}})
         self.optimizer = getattr(torch.optim, opt["target"].rsplit(".", 1)[-1])(groups, **opt.get("params", {}))

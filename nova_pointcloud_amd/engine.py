@@ -270,10 +270,10 @@ class NovaEngine(object):
                 q = pack.fp8 = pack_vit_blocks_fp8(pack.modules)
             # delayed scaling of the MLP hidden rows (per lane and stack): the scale of this call comes from the largest |GELU|
             # the previous call of the same stack saw (x 2 headroom; e4m3 saturates beyond); the first call guesses 64 / 448
-            state = ws.setdefault("q8", {}).get(id(pack))
+            state = ws.setdefault("q8", {}).get(pack)  # keyed by the pack object (kept alive by the key), not by a reusable id()
             if state is None and self.fp8_delayed:
                 n = len(pack.arr)
-                state = ws["q8"][id(pack)] = (torch.full((n,), 64.0 / 448.0, dtype=_F32, device=self.dev),
+                state = ws["q8"][pack] = (torch.full((n,), 64.0 / 448.0, dtype=_F32, device=self.dev),
                                               torch.zeros(n, dtype=torch.int32, device=self.dev))
             sc, am = state if self.fp8_delayed else (None, None)
             hip.call("nova_vit_blocks_forward_fp8", pack.arr, q.arr, len(pack.arr), x.data_ptr(), S, L, self.D, self.heads, self.hidden,
@@ -567,6 +567,9 @@ class NovaEngine(object):
         mod_bytes = steps * S * nmax * (3 * self.dec.depth + 2) * D * prompt.element_size()
         mod_steps = steps if (steps > 1 and mod_bytes <= self.MOD_HOIST_BYTES and not inputs.get("per_step_adaln", False)) else 1
         ws = self._workspace(S, B, N, max(L2, Lp + Nv), nmax, ctx["k"], mod_steps)
+        # fp8 delayed-scaling state is per call: every generation starts from the documented first-step guess (64 / 448) and adapts
+        # from its own earlier AR steps, so a seeded call gives the same points whatever ran before it on this engine
+        ws.pop("q8", None)
         code, st = self.code, hip.stream_ptr
         extra_kind = (1 if scaler.image_guidance_scale else 2) if passes == 3 else 0
         extra_scale = float(scaler.image_guidance_scale or scaler.spatiotemporal_guidance_scale) if passes == 3 else 0.0

@@ -23,6 +23,10 @@ def _points(t, name):
         raise hip.NovaHipError(f"{name}: point-set metrics run on the GPU (got {'a CPU tensor' if torch.is_tensor(t) else type(t).__name__})")
     if t.dim() != 3 or t.shape[-1] != 3:
         raise ValueError(f"{name}: expected [B, n, 3] points, got {tuple(t.shape)}")
+    if t.requires_grad and torch.is_grad_enabled():
+        # evaluation metrics: the HIP distance kernels have no backward, so a loss built on them would silently carry no gradient
+        raise hip.NovaHipError(f"{name}: nova_pointcloud_amd.metrics is evaluation-only (no autograd through the HIP kernels); "
+                               "detach the points or compute a training loss in PyTorch")
     return t.detach().float().contiguous()
 
 

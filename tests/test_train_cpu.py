@@ -163,6 +163,40 @@ def test_trainer_loop_checkpoints_and_resume(tmp_path):
         model({"x": torch.zeros(1, 3, 4, 4), "prompt": [torch.zeros(2, 32)]})
 
 
+def test_resumed_trainer_continues_the_saved_ema(tmp_path):
+    """The EMA written beside a checkpoint is what a resumed run averages on from (reference engine/train_engine.py:52-56), not a
+    fresh copy of the resumed raw weights; and a checkpoint stored the reference's way (diffusion_pytorch_model.bin) loads."""
+    from diffnext.engine import engine_utils
+    from diffnext.engine.train_engine import Trainer
+    from diffnext.models.transformers.transformer_nova import NOVATransformer3DModel
+    from diffnext.schedulers import FlowMatchEulerDiscreteScheduler
+
+    engine_utils.manual_seed(11)
+    cfg = tiny_config(tmp_path, steps=4)
+    cfg["ema"] = {"params": {"decay": 0.5, "update_every": 1}}
+    first = Trainer(cfg, tiny_model(), FixedBatch(), noise_scheduler=FlowMatchEulerDiscreteScheduler())
+    first.train_loop()
+    ckpt = tmp_path / "checkpoints" / "checkpoint-4"
+    ema_saved = {k: v.clone() for k, v in first.ema.model.state_dict().items()}
+    raw_saved = first.model.state_dict()
+    assert any(not torch.equal(ema_saved[k].float(), raw_saved[k].float()) for k in ema_saved)  # the average lags the weights
+    cfg2 = tiny_config(tmp_path, steps=5)
+    cfg2["ema"] = cfg["ema"]
+    cfg2["experiment"].update(resume_from_checkpoint=str(ckpt), resume_iter=4)
+    resumed = Trainer(cfg2, NOVATransformer3DModel.from_pretrained(str(ckpt / "transformer")), FixedBatch(),
+                      noise_scheduler=FlowMatchEulerDiscreteScheduler())
+    for k, v in resumed.ema.model.state_dict().items():
+        assert torch.equal(v.float(), ema_saved[k].float()), k
+    # the reference's on-disk format: a torch.save'd state_dict named diffusion_pytorch_model.bin
+    legacy = tmp_path / "legacy"
+    legacy.mkdir()
+    (legacy / "config.json").write_text((ckpt / "transformer" / "config.json").read_text())
+    torch.save(dict(raw_saved), legacy / "diffusion_pytorch_model.bin")
+    again = NOVATransformer3DModel.from_pretrained(str(legacy))
+    for k, v in again.state_dict().items():
+        assert torch.equal(v, raw_saved[k]), k
+
+
 def test_train_script_runs_and_resumes(tmp_path):
     import yaml
 

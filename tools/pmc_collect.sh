@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 counter passes over tools/pmc_kernels.py (run on the GPU box from the repo root):
 #   bash tools/pmc_collect.sh gpurun_out/r2/pmc
-# One pass per counter group (SQ has 8 slots; FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md
+# One pass per counter group (SQ has 8 slots, TCC 4; FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md
 # "rocprofv3 PMC slots"), counters with --kernel-trace only, the program directly after `--`. Then:
 #   python3 tools/pmc_summary.py gpurun_out/r2/pmc profiles/r02_pmc.json
 set -euo pipefail
@@ -18,6 +18,7 @@ run() {  # name, counters...
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_TRANS_F32 SQ_WAVES
 run grbm GRBM_GUI_ACTIVE
+run tcc TCC_HIT_sum TCC_MISS_sum
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- python3 "$ROOT/tools/pmc_kernels.py" > "$OUT/trace.log" 2>&1

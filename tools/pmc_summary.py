@@ -10,6 +10,9 @@ Per kernel (mean over the dispatches after the first = warm-up): raw counters, l
   mfma_pipe_util   SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8): share of SIMD-cycles with the matrix pipe busy
   valu_active, wait_any, wait_inst, active_any: shares of SQ_WAVE_CYCLES (all quad-cycle counters)
   mfma_valu_coexec SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES
+  l2_hit           TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)   (per-XCD L2; MI355X_MICROARCH.md "L2")
+  operand_bytes, out_bytes, fetch_over_operands, hbm_over_algorithmic: against the algorithmic bytes of the standard shape
+A third argument writes the DESIGN.md table (markdown) generated from the same numbers.
 The file carries the sha256 of the kernel sources it was measured on; bench.py ignores it when the sources have changed.
 """
 import csv
@@ -65,6 +68,25 @@ def mean_skip_first(d):
     return sum(vals) / len(vals)
 
 
+# algorithmic bytes of one launch at the standard shape (S = 64 x L = 2560 rows, D = 1024, 16 heads, bf16): (operands read, output written)
+ROWS, D_ = 64 * 2560, 1024
+ALGO = {
+    "gemm256p_kernel<bf16,0>": None,  # proj (K = 1024) and fc2 (K = 4096) share this name: reported per launch mix, no single figure
+    "gemm256p_kernel<bf16,1>": (ROWS * D_ * 2 + 4 * D_ * D_ * 2, ROWS * 4 * D_ * 2),          # fc1 + GELU
+    "gemm256p_kernel<bf16,3>": (ROWS * D_ * 2 + 3 * D_ * D_ * 2 + 2560 * 64 * 4, ROWS * 3 * D_ * 2),  # QKV + RoPE (one table)
+    "attn": (ROWS * 3 * D_ * 2, ROWS * D_ * 2),
+    "row_norm": (2 * ROWS * D_ * 2, ROWS * D_ * 2),
+}
+
+
+def algo_for(k):
+    if k.startswith("attn_"):
+        return ALGO["attn"]
+    if k.startswith("row_norm"):
+        return ALGO["row_norm"]
+    return ALGO.get(k)
+
+
 def main():
     root, out_path = sys.argv[1], sys.argv[2]
     acc, dur = counters(root), durations(root)
@@ -98,6 +120,12 @@ def main():
         if act is not None and g("SQ_WAIT_ANY") is not None and g("SQ_WAIT_INST_ANY") is not None:
             tot = act + g("SQ_WAIT_ANY") + g("SQ_WAIT_INST_ANY")  # ~ SQ_WAVE_CYCLES of that pass (disjoint buckets)
             rec.update(active_any=round(act / tot, 4), wait_any=round(g("SQ_WAIT_ANY") / tot, 4), wait_inst=round(g("SQ_WAIT_INST_ANY") / tot, 4))
+        if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+            rec["l2_hit"] = round(g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")), 4)
+        al = algo_for(k)
+        if al and "fetch_bytes" in rec:
+            rec.update(operand_bytes=al[0], out_bytes=al[1], fetch_over_operands=round(rec["fetch_bytes"] / al[0], 2),
+                       hbm_over_algorithmic=round(rec["hbm_bytes"] / (al[0] + al[1]), 2))
         kernels[k] = rec
     doc = {"source_sha256": source_hash(), "shape": "one ViT block, S=64 x L=2560, D=1024, 16 heads, bf16 (tools/pmc_kernels.py)",
            "units": __doc__.split("Per kernel")[1].strip(), "kernels": kernels}
@@ -105,6 +133,15 @@ def main():
         json.dump(doc, f, indent=1, sort_keys=True)
     for k, r in kernels.items():
         print(k, {a: b for a, b in r.items() if a != "counters"})
+    if len(sys.argv) > 3:  # the DESIGN.md table, generated (never typed by hand)
+        rows = ["| kernel | us | clock GHz | matrix pipe busy | VALU per MFMA | active / issue-stall / wait | L2 hit | fabric fetch / operands | HBM bytes / algorithmic |",
+                "|---|---|---|---|---|---|---|---|---|"]
+        pc = lambda v: "-" if v is None else f"{100 * v:.1f} %"
+        for k, r in kernels.items():
+            shares = "-" if "active_any" not in r else f"{100 * r['active_any']:.0f} / {100 * r['wait_inst']:.0f} / {100 * r['wait_any']:.0f} %"
+            rows.append(f"| `{k}` | {r.get('duration_us', '-')} | {r.get('clock_ghz', '-')} | {pc(r.get('mfma_pipe_util'))} | {r.get('valu_per_mfma', '-')} | {shares} | "
+                        f"{pc(r.get('l2_hit'))} | {r.get('fetch_over_operands', '-')} | {r.get('hbm_over_algorithmic', '-')} |")
+        open(sys.argv[3], "w").write("\n".join(rows) + "\n")
 
 
 if __name__ == "__main__":
