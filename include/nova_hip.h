@@ -138,6 +138,19 @@ int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void
                   float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, int head_dim,
                   long qkv_row_stride, long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream);
 
+/* ---- training: backward of the LayerNorm family --------------------------------------------------------------------
+ * For y = LN(x; eps) [* gamma + beta] [* (1 + scale) + shift] [* gate] [+ res] (nova_row_norm's forward) and the output
+ * gradient dy [rows, D]: dx [rows, D]; d_scale / d_shift / d_gate written into dmod [rows, mod_ld] at the forward's offsets
+ * (dmod may be NULL when mod is); the parameter gradients as `parts` partial rows d_gamma_part / d_beta_part [parts, D] f32
+ * that the caller sums over dim 0 (one row per wave of the launch: parts % 4 == 0, parts / 4 workgroups; no atomics, so
+ * the result is bitwise reproducible); d_res = dy is the caller's. Statistics are recomputed from x. Replaces the
+ * autograd of nn.LayerNorm + residual in Block.forward (vision_transformer.py:78-82,91-92), of AdaLayerNormZero.forward
+ * (normalization.py:34-36) and of DiffusionBlock's `norm2(h) * gate + x` (diffusion_mlp.py:52-53) in the training
+ * forward/backward (transformer_3d.py:79-100,166-190). */
+int nova_row_norm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* mod, long mod_ld,
+                      int scale_off, int shift_off, int gate_off, void* dx, void* dmod, float* dgamma_part, float* dbeta_part,
+                      int parts, long rows, int D, float eps, int dtype, void* stream);
+
 /* ---- LayerNorm family -----------------------------------------------------------------------
  * y = LN(in[gather ? gather[r] : r]; eps) [* gamma + beta] [* (1 + mod[r, scale_off..]) +
  * mod[r, shift_off..]] [* mod[r, gate_off..]] [+ res[r]] -> out[r]. Offsets < 0 disable a term.

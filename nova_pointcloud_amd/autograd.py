@@ -2,8 +2,13 @@
 
 `attention(q, k, v)` is F.scaled_dot_product_attention (no mask, no dropout) for bf16 device tensors with head_dim 64 / 96:
 forward on `attn_bf16` with the row log-sum-exp kept, backward on `attn_bwd_dq` / `attn_bwd_dkv` (csrc/attn_bwd.hip;
-reference vision_transformer.py:63 under the training forward transformer_3d.py:79-100). Everything else of the
-training step stays on PyTorch's ROCm libraries (plain GEMMs, LayerNorm, GELU).
+reference vision_transformer.py:63 under the training forward transformer_3d.py:79-100).
+
+`fused_norm(x, ...)` is the LayerNorm family of the blocks as ONE row kernel forward and ONE backward (csrc/rowops.hip,
+csrc/rownorm_bwd.hip): y = LN(x) [* gamma + beta] [* (1 + scale) + shift] [* gate] [+ res] - the post-norm residual of a ViT
+block (vision_transformer.py:78-82,91-92), AdaLayerNormZero's modulate (normalization.py:34-36) and DiffusionBlock's gated norm
+(diffusion_mlp.py:52-53) - for f32 / bf16 / f16 device tensors. The plain GEMMs and the pointwise activations of the training
+step stay on PyTorch's ROCm libraries.
 """
 import math
 import os
@@ -57,3 +62,113 @@ class NovaAttentionFunction(torch.autograd.Function):
 def attention(q, k, v):
     """softmax(q k^T / sqrt(d)) v for [S, heads, L, 64 | 96] bf16 device tensors, differentiable."""
     return NovaAttentionFunction.apply(q, k, v)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+_NORM_ENABLED = os.environ.get("NOVA_TRAIN_NORM", "1") != "0"  # read once
+stats["norm_calls"] = 0
+_PARTS = 1024  # partial rows of d_gamma / d_beta (= waves of the backward launch)
+
+
+def _rows2d(t, D):
+    """[..., D] view -> [rows, D] view (no copy) or None when the leading dims do not collapse."""
+    if t.dim() == 2:
+        return t
+    try:
+        return t.view(-1, D) if t.is_contiguous() else t.flatten(0, -2) if t.flatten(0, -2).data_ptr() == t.data_ptr() else None
+    except RuntimeError:
+        return None
+
+
+def _mod_layout(mods, D):
+    """scale / shift / gate as the kernels address them: (pointer of the lowest view, row pitch in elements, {name: column offset}).
+    They must be [rows, D] views (unit last stride, one common row pitch) of ONE buffer, all inside one row span - what
+    `proj(...).chunk(n, dim=-1)` yields (normalization.py:35). None otherwise."""
+    views = {k: _rows2d(t, D) for k, t in mods.items()}
+    if any(v is None or v.stride(1) != 1 for v in views.values()):
+        return None
+    first = next(iter(views.values()))
+    ld, rows = first.stride(0), first.shape[0]
+    vec = 4 if first.dtype == torch.float32 else 8
+    if ld % vec or any(v.stride(0) != ld or v.shape[0] != rows or v.untyped_storage().data_ptr() != first.untyped_storage().data_ptr()
+                       for v in views.values()):
+        return None
+    lo = min(v.storage_offset() for v in views.values())
+    offs = {k: v.storage_offset() - lo for k, v in views.items()}
+    if any(o % vec or o + D > ld for o in offs.values()):
+        return None
+    ptr = first.untyped_storage().data_ptr() + lo * first.element_size()
+    return ptr, ld, offs, rows
+
+
+def fused_norm_supported(x, gamma=None, scale=None, shift=None, gate=None, res=None):
+    """Device rows of width <= 2048 (a multiple of the 16-byte vector), modulation terms given as views of ONE row-major buffer."""
+    if not (_NORM_ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16)):
+        return False
+    D = x.shape[-1]
+    vec = 4 if x.dtype == torch.float32 else 8
+    if D % vec or D > 2048 or (scale is None) != (shift is None):
+        return False
+    mods = {k: t for k, t in (("scale", scale), ("shift", shift), ("gate", gate)) if t is not None}
+    if mods:
+        if any(t.dtype != x.dtype or t.shape[-1] != D or t.numel() != x.numel() for t in mods.values()):
+            return False
+        if _mod_layout(mods, D) is None:
+            return False
+    return res is None or (res.dtype == x.dtype and res.shape == x.shape)
+
+
+class NovaFusedNormFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, scale, shift, gate, res, eps):
+        hip.load()
+        stats["norm_calls"] += 1
+        shape, D = x.shape, x.shape[-1]
+        x2 = x.reshape(-1, D).contiguous()
+        rows = x2.shape[0]
+        mods = {k: t for k, t in (("scale", scale), ("shift", shift), ("gate", gate)) if t is not None}
+        mptr, ld, offs = None, 0, {}
+        if mods:
+            lay = _mod_layout(mods, D)
+            if lay is None or lay[3] != rows:
+                raise ValueError("fused_norm: scale / shift / gate must be [rows, D] views of one row-major buffer (see fused_norm_supported)")
+            mptr, ld, offs, _ = lay
+        o = lambda k: offs.get(k, -1)
+        res2 = None if res is None else res.reshape(-1, D).contiguous()
+        g32 = None if gamma is None else gamma.detach().float().contiguous()
+        b32 = None if beta is None else beta.detach().float().contiguous()
+        out = torch.empty_like(x2)
+        hip.call("nova_row_norm", x2.data_ptr(), out.data_ptr(), hip.ptr(g32), hip.ptr(b32), mptr, ld, o("scale"), o("shift"), o("gate"),
+                 hip.ptr(res2), None, rows, D, float(eps), hip.dtype_code(x.dtype), hip.stream_ptr())
+        ctx.save_for_backward(x2, g32, b32, *mods.values())  # the views keep the modulation buffer alive (and versioned)
+        ctx.meta = (shape, tuple(mods), float(eps), None if gamma is None else gamma.dtype, res is not None)
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g32, b32, *mod_t = ctx.saved_tensors
+        shape, names, eps, gdtype, has_res = ctx.meta
+        D, rows = shape[-1], x2.shape[0]
+        mods = dict(zip(names, mod_t))
+        mptr, ld, offs, dmod = None, 0, {}, None
+        if mods:
+            mptr, ld, offs, _ = _mod_layout(mods, D)
+            dmod = torch.empty(rows, ld, dtype=x2.dtype, device=x2.device)
+        o = lambda k: offs.get(k, -1)
+        dy2 = dy.reshape(-1, D).to(x2.dtype).contiguous()
+        dx = torch.empty_like(x2)
+        parts = min(_PARTS, max(4, ((rows + 3) // 4) * 4))
+        dgp = dbp = None
+        if g32 is not None:
+            dgp = torch.empty(parts, D, dtype=torch.float32, device=x2.device)
+            dbp = torch.empty(parts, D, dtype=torch.float32, device=x2.device)
+        hip.call("nova_row_norm_bwd", x2.data_ptr(), dy2.data_ptr(), hip.ptr(g32), hip.ptr(b32), mptr, ld, o("scale"), o("shift"), o("gate"),
+                 dx.data_ptr(), hip.ptr(dmod), hip.ptr(dgp), hip.ptr(dbp), parts, rows, D, eps, hip.dtype_code(x2.dtype), hip.stream_ptr())
+        grad = lambda k: dmod[:, offs[k]:offs[k] + D].reshape(mods[k].shape) if k in mods else None
+        return (dx.view(shape), None if g32 is None else dgp.sum(0).to(gdtype), None if g32 is None else dbp.sum(0).to(gdtype),
+                grad("scale"), grad("shift"), grad("gate"), dy if has_res else None, None)
+
+
+def fused_norm(x, gamma=None, beta=None, scale=None, shift=None, gate=None, res=None, eps=1e-5):
+    """y = LN(x; eps) [* gamma + beta] [* (1 + scale) + shift] [* gate] [+ res], differentiable; one HIP row kernel each way."""
+    return NovaFusedNormFunction.apply(x, gamma, beta, scale, shift, gate, res, eps)

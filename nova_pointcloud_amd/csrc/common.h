@@ -148,6 +148,36 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// The same arithmetic on the 4 values a lane holds of one accumulator fragment, written on float pairs so that the
+// polynomial, the 1 + e and the final product become v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 (two values per issue;
+// every element goes through the same single-rounded operations in the same order as gelu_erf_fast, so the results are
+// bit-identical). The epilogue runs with the matrix pipe idle, where every vector issue is paid in full.
+__device__ __forceinline__ f4v gelu_erf_fast4(f4v x) {
+  f4v out;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f2v xx = {x[2 * h], x[2 * h + 1]};
+    f2v x2 = xx * xx;
+    x2 = f2v{fminf(x2[0], 64.0f), fminf(x2[1], 64.0f)};
+    f2v q = __builtin_elementwise_fma(f2v{1.0142630601e-3f, 1.0142630601e-3f}, x2, f2v{-1.0677572399e-1f, -1.0677572399e-1f});
+    q = __builtin_elementwise_fma(q, x2, f2v{-2.3011213396e+0f, -2.3011213396e+0f});
+    const f2v z = q * xx;
+    const f2v s = f2v{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + f2v{1.0f, 1.0f};
+    const f2v r = xx * f2v{__builtin_amdgcn_rcpf(s[0]), __builtin_amdgcn_rcpf(s[1])};
+    out[2 * h] = r[0];
+    out[2 * h + 1] = r[1];
+  }
+  return out;
+}
+
+// RoPE rotation of the two adjacent pairs a lane holds of one accumulator fragment (embeddings.py:36-43): (x0, x1) -> (c0 x0 - s0 x1,
+// s0 x0 + c0 x1), likewise (x2, x3) with (c1, s1); t = (c0, s0, c1, s1). One function for every GEMM epilogue, so the tile
+// structures stay bit-identical. (A v_pk_mul_f32 + v_pk_fma_f32 form with op_sel / neg_lo modifiers - half the issues - measured
+// SLOWER in the persistent kernel: rotate / no-rotate time ratio 1.146 against 1.107 for this scalar form, round 3.)
+__device__ __forceinline__ f4v rope_rotate4(f4v x, f4v t) {
+  return f4v{t[0] * x[0] - t[1] * x[1], t[1] * x[0] + t[0] * x[1], t[2] * x[2] - t[3] * x[3], t[3] * x[2] + t[2] * x[3]};
+}
+
 // XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a
 // contiguous chunk of the logical tile list, so neighbouring tiles hit the same per-XCD L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

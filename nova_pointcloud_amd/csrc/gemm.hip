@@ -165,17 +165,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
       f4v v = acc[nf][mf];
       if (EPI == EPI_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? v[j] : gelu_erf(v[j]);
+        if (sizeof(T) == 2) v = gelu_erf_fast4(v);
       } else if (EPI == EPI_SILU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
       } else if (EPI == EPI_ROPE) {
         if (rot) {  // pairs (n, n+1), (n+2, n+3); cs = cos0, sin0, cos1, sin1
-          const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-          v[0] = cs[nf][0] * x0 - cs[nf][1] * x1;
-          v[1] = cs[nf][1] * x0 + cs[nf][0] * x1;
-          v[2] = cs[nf][2] * x2 - cs[nf][3] * x3;
-          v[3] = cs[nf][3] * x2 + cs[nf][2] * x3;
+          v = rope_rotate4(v, cs[nf]);
         }
         if (n0 < e.q_cols) v = v * e.q_scale;  // tile-uniform like `rot`
       }

@@ -273,17 +273,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
       f4v v = acc[nf][mf];
       if (EPI == E_GELU) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? gelu_erf_fast(v[j]) : gelu_erf(v[j]);
+        for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? v[j] : gelu_erf(v[j]);
+        if (sizeof(T) == 2) v = gelu_erf_fast4(v);
       } else if (EPI == E_SILU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
       } else if (EPI == E_ROPE) {
         if (rot) {
-          const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-          v[0] = cs[nf][0] * x0 - cs[nf][1] * x1;
-          v[1] = cs[nf][1] * x0 + cs[nf][0] * x1;
-          v[2] = cs[nf][2] * x2 - cs[nf][3] * x3;
-          v[3] = cs[nf][3] * x2 + cs[nf][2] * x3;
+          v = rope_rotate4(v, cs[nf]);
         }
         if (n0 < e.q_cols) v = v * e.q_scale;
       }
@@ -565,10 +562,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
           uint32_t d[4];  // this lane's 4 columns of every 16-column fragment as 4 e4m3 bytes
 #pragma unroll
           for (int nf = 0; nf < 4; ++nf) {
-            f4v v = acc[nf][mf];
+            f4v v = gelu_erf_fast4(acc[nf][mf]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              v[q] = gelu_erf_fast(v[q]);
               q8_max = fmaxf(q8_max, fabsf(v[q]));
               v[q] = __builtin_amdgcn_fmed3f(v[q] * q8_inv, -448.0f, 448.0f);
             }
@@ -593,18 +589,14 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
           f4v v = acc[nf][mf];
           if (EPI == E_GELU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = sizeof(OT) == 2 ? gelu_erf_fast(v[q]) : gelu_erf(v[q]);
+            for (int q = 0; q < 4; ++q) v[q] = sizeof(OT) == 2 ? v[q] : gelu_erf(v[q]);
+            if (sizeof(OT) == 2) v = gelu_erf_fast4(v);
           } else if (EPI == E_SILU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
           } else if (EPI == E_ROPE) {
             if constexpr (ROT) {
-              const f4v t = cs[g][j][nf];
-              const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-              v[0] = t[0] * x0 - t[1] * x1;
-              v[1] = t[1] * x0 + t[0] * x1;
-              v[2] = t[2] * x2 - t[3] * x3;
-              v[3] = t[3] * x2 + t[2] * x3;
+              v = rope_rotate4(v, cs[g][j][nf]);
             }
             v = v * qmul;
           }

@@ -109,8 +109,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const T* __restrict__ 
     if (m < M) {
       f4v v = acc[rb];
       if (EPI == 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf_fast(v[j]);
+        v = gelu_erf_fast4(v);
       } else if (EPI == 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);

@@ -39,3 +39,10 @@ def autograd():
 def train_attention_supported(q, attn_mask):
     """bf16 device tensors [S, heads, L, 64 | 96] without a mask: the case the HIP attention backward is built for."""
     return q.is_cuda and autograd().attention_supported(q, attn_mask)
+
+
+def train_norm_supported(x, **terms):
+    """Training on the GPU (autograd on): the LayerNorm family as one HIP row kernel each way (autograd.fused_norm)."""
+    import torch
+
+    return x.is_cuda and torch.is_grad_enabled() and autograd().fused_norm_supported(x, **terms)

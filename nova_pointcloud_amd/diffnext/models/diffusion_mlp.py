@@ -78,6 +78,9 @@ class DiffusionBlock(nn.Module):
         else:
             h, (gate,) = self.norm1(x, z)
             h = self.proj(h)
+        if _backend.train_norm_supported(h, gamma=self.norm2.weight, gate=gate, res=x):
+            # training on the GPU: norm2(h) * gate + x as one HIP row kernel each way (csrc/rownorm_bwd.hip)
+            return _backend.autograd().fused_norm(h, gamma=self.norm2.weight, beta=self.norm2.bias, gate=gate, res=x, eps=self.norm2.eps)
         return self.norm2(h) * gate + x
 
 

@@ -10,6 +10,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from .. import _backend
 from .. import _torch_ops as ops
 
 
@@ -37,6 +38,9 @@ class AdaLayerNormZero(nn.Module):
 
     def forward(self, x, z) -> Tuple[torch.Tensor, Tuple[torch.Tensor]]:
         scale, shift, *rest = self.statistics(z)
+        if isinstance(self.norm, nn.LayerNorm) and _backend.train_norm_supported(x, scale=scale, shift=shift):
+            # training on the GPU: affine-free LayerNorm + modulate as one HIP row kernel each way (csrc/rownorm_bwd.hip)
+            return _backend.autograd().fused_norm(x, scale=scale, shift=shift, eps=self.norm.eps), tuple(rest)
         return ops.adaln_modulate(self.norm(x), scale, shift), tuple(rest)
 
 

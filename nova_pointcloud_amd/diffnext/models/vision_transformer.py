@@ -141,8 +141,22 @@ class Block(nn.Module):
         self.attn.pe_func = pe_func
         if use_hip(x) and _plain_attention(self.attn):
             return _backend.engine().block_stack_forward([self], x, pe_func)
+        if _backend.train_norm_supported(x, gamma=self.norm1.weight, res=x):
+            # training on the GPU: branch + LayerNorm + residual, the norm and the add as ONE row kernel forward and ONE backward
+            # (csrc/rowops.hip, csrc/rownorm_bwd.hip) - the same arithmetic as the two lines below
+            return self._post_norm_fused(self._post_norm_fused(x, "attn"), "mlp")
         x = x + self.forward_ckpt(x, "attn")
         return x + self.forward_ckpt(x, "mlp")
+
+    def _post_norm_fused(self, x, name):
+        inner, norm = (self.attn, self.norm1) if name == "attn" else (self.mlp, self.norm2)
+        fused = _backend.autograd().fused_norm
+
+        def branch(t):
+            return fused(inner(t), gamma=norm.weight, beta=norm.bias, res=t, eps=norm.eps)
+
+        recompute = getattr(self, name + "_checkpointing", False) and x.requires_grad
+        return checkpoint(branch, x, use_reentrant=False) if recompute else branch(x)
 
 
 class VisionTransformer(nn.Module):

@@ -258,7 +258,12 @@ class NovaEngine(object):
                       df=e(S * nmax, D), dg=e(S * nmax, D), dmod=e(steps * S * nmax, (3 * self.dec.depth + 2) * D),
                       # operands of nova_decoder_denoise at addresses that do not change from call to call (its launch
                       # sequence is replayed as a hipGraph keyed by its arguments): condition rows and the rows being denoised
-                      dz=e(S * nmax, D), dx=torch.empty(B * nmax * self.P, dtype=_F32, device=dev), temb={})
+                      dz=e(S * nmax, D), dx=torch.empty(B * nmax * self.P, dtype=_F32, device=dev), temb={},
+                      # per-AR-step temporaries of the hot loop (flat, viewed at the step's sizes): no allocator call per step
+                      ids_prev=torch.empty(B * N, dtype=torch.int64, device=dev), ids_pred=torch.empty(B * nmax, dtype=torch.int64, device=dev),
+                      ids_cat=torch.empty(S * nmax, dtype=torch.int64, device=dev), rope1=torch.empty(B * L * (D // self.heads), dtype=_F32, device=dev),
+                      rope_q=torch.empty(B * nmax * (D // self.heads), dtype=_F32, device=dev), lq=e(S * nmax, D), lx=e(S * nmax, D), lo=e(S * nmax, D),
+                      lh=e(S * nmax, self.hidden), lz=e(S * nmax, D), lz2=e(S * nmax, D))
             self.ws[lane] = (key, ws)
         return self.ws[lane][1]
 
@@ -295,9 +300,9 @@ class NovaEngine(object):
         hip.call("nova_gemm_bias_act", a.data_ptr(), w_ptr, b_ptr, out.data_ptr(), M, N, K, act, self.code, hip.stream_ptr())
         return out
 
-    def _norm_rows(self, x, gb, gather=None, rows=None, eps=1e-5):
+    def _norm_rows(self, x, gb, gather=None, rows=None, eps=1e-5, out=None):
         rows = (gather.numel() if gather is not None else x.shape[0]) if rows is None else rows
-        out = torch.empty(rows, self.D, dtype=x.dtype, device=x.device)
+        out = torch.empty(rows, self.D, dtype=x.dtype, device=x.device) if out is None else out
         hip.call("nova_row_norm", x.data_ptr(), out.data_ptr(), gb[0], gb[1], None, 0, -1, -1, -1, None, hip.ptr(gather),
                  rows, self.D, eps, self.code, hip.stream_ptr())
         return out
@@ -315,22 +320,22 @@ class NovaEngine(object):
         kv = ws["qkv"].view(-1)[: S * L * 2 * D].view(S * L, 2 * D)
         hip.call("nova_qkv_rope_cols", x2.data_ptr(), lp.kv[0], lp.kv[1], hip.ptr(rope_full), kv.data_ptr(), S * L, 2 * D, D,
                  L, 1, hd, D, code, st())
-        # the predicted rows of every sequence (cond and uncond share pred_ids)
-        ids = torch.cat([pred_ids] * (S // B)).contiguous()  # [S, n]: every guidance pass predicts the same tokens
-        xq = torch.empty(S * n, D, dtype=x2.dtype, device=x2.device)
+        # the predicted rows of every sequence (cond and uncond share pred_ids); every temporary is a workspace slot
+        rows = S * n
+        ids = ws["ids_cat"][:rows].view(S, n)  # [S, n]: every guidance pass predicts the same tokens
+        ids.view(S // B, B, n).copy_(pred_ids)
+        xq, q, o, a = (ws[k][:rows] for k in ("lx", "lq", "lo", "lz"))
         hip.call("nova_build_sequence", None, 0, x2.data_ptr() + Nv * D * es, L, ids.data_ptr(), xq.data_ptr(), S, S, 0, n, D,
                  code, st())
-        rope_q = hip.rope_table(pos_img, pred_ids, 0, inv_freq, B, hd) if pos_img is not None else None
-        q = torch.empty(S * n, D, dtype=x2.dtype, device=x2.device)
+        rope_q = hip.rope_table(pos_img, pred_ids, 0, inv_freq, B, hd, out=ws["rope_q"]) if pos_img is not None else None
         hip.call("nova_qkv_rope_cols", xq.data_ptr(), lp.q[0], lp.q[1], hip.ptr(rope_q), q.data_ptr(), S * n, D, D, n,
                  B if rope_q is not None else 1, hd, D, code, st())
-        o = torch.empty_like(q)
         hip.call("nova_attn_fwd", q.data_ptr(), kv.data_ptr(), kv.data_ptr() + D * es, o.data_ptr(), S, self.heads, n, L, hd,
                  D, 2 * D, D, float(hd) ** -0.5, code, st())
-        a = self._gemm(o, lp.proj[0], lp.proj[1], D)
+        self._gemm(o, lp.proj[0], lp.proj[1], D, out=a)
         hip.call("nova_row_norm", a.data_ptr(), xq.data_ptr(), lp.n1[0], lp.n1[1], None, 0, -1, -1, -1, xq.data_ptr(), None, S * n,
                  D, 1e-5, code, st())
-        h = self._gemm(self._gemm(xq, lp.fc1[0], lp.fc1[1], self.hidden, hip.ACT_GELU_ERF), lp.fc2[0], lp.fc2[1], D)
+        h = self._gemm(self._gemm(xq, lp.fc1[0], lp.fc1[1], self.hidden, hip.ACT_GELU_ERF, out=ws["lh"][:rows]), lp.fc2[0], lp.fc2[1], D, out=a)
         hip.call("nova_row_norm", h.data_ptr(), xq.data_ptr(), lp.n2[0], lp.n2[1], None, 0, -1, -1, -1, xq.data_ptr(), None, S * n,
                  D, 1e-5, code, st())
         return xq
@@ -585,7 +590,7 @@ class NovaEngine(object):
         temb.copy_(self.timestep_table(timesteps))
 
         # ---- positions / absolute position tables
-        rope_i = pos_img = inv_freq = inv_freq_v = img_pe = vpos = None
+        rope_i = rope_i0 = pos_img = inv_freq = inv_freq_v = img_pe = vpos = None
         hd = D // self.heads
         rotary = m.image_pos_embed is not None
         if rotary:
@@ -594,6 +599,7 @@ class NovaEngine(object):
             inv_freq = m.image_pos_embed.inv_freq().to(device=dev, dtype=_F32).contiguous()
             inv_freq_v = m.video_pos_embed.inv_freq().to(device=dev, dtype=_F32).contiguous()
             rope_i = hip.rope_table(pos_img, None, Nv, inv_freq, 1, hd)
+            rope_i0 = rope_i[:, :Nv].contiguous()  # the first AR step's table (condition prefix only)
         else:  # abs-PE: tokens + time_embed[t] + sincos (transformer_3d.py:154, embeddings.py:103-115)
             vpe = m.video_pos_embed
             frame = (torch.arange(T, dtype=_F32) / (T / vpe.base_t)).view(-1, 1)
@@ -669,15 +675,17 @@ class NovaEngine(object):
                 z0 = ws["z0"]
                 hip.call("nova_embed_canvas", canvas.data_ptr(), mask.data_ptr(), self.patch[0], self.patch[1], self.mask_token,
                          hip.ptr(img_pe), z0.data_ptr(), B, N, P, D, code, st())
-                prev_ids = order[:, :done].contiguous()
-                pred_ids = order[:, done : done + n].contiguous()
+                prev_ids = ws["ids_prev"][: B * done].view(B, done)
+                prev_ids.copy_(order[:, :done])
+                pred_ids = ws["ids_pred"][: B * n].view(B, n)
+                pred_ids.copy_(order[:, done : done + n])
                 mask.scatter_(1, pred_ids, 0.0)
                 # first half: [c ; known tokens in generation order]
                 L1 = Nv + done
                 x1 = ws["x1"][: S * L1]
                 self._sequence(x1, c, Nv, z0, N, prev_ids if done else None, S, B, Nv, done)
-                rope1 = hip.rope_table(pos_img, prev_ids, Nv, inv_freq, B, hd) if (rotary and done) else (
-                    rope_i[:, :Nv].contiguous() if rotary else None)
+                rope1 = hip.rope_table(pos_img, prev_ids, Nv, inv_freq, B, hd, out=ws["rope1"]) if (rotary and done) else (
+                    rope_i0 if rotary else None)
                 self._blocks(self.enc1, x1, S, L1, rope1, B if (rotary and done) else 1, ws)
                 # second half: [c' ; full canvas with the known tokens scattered back]
                 x2 = ws["x2"][: S * L2]
@@ -688,9 +696,9 @@ class NovaEngine(object):
                     self._blocks(self.enc2_head, x2, S, L2, rope_i, 1, ws)
                 y = self._last_block_rows(x2, S, B, L2, Nv, n, pred_ids, pos_img, inv_freq, rope_i, hd, ws)
                 # final LN only on the rows predicted now, then the condition projection (time term added per step)
-                zc = self._norm_rows(y, self.inorm)
+                zc = self._norm_rows(y, self.inorm, out=ws["lz"][: S * n])
                 w1, b1, w2, b2 = self.dec.time[1]
-                zc = self._gemm(self._gemm(zc, w1, b1, D, hip.ACT_SILU), w2, b2, D, out=ws["dz"][: S * n])
+                zc = self._gemm(self._gemm(zc, w1, b1, D, hip.ACT_SILU, out=ws["lz2"][: S * n]), w2, b2, D, out=ws["dz"][: S * n])
                 # this step's noise rows (drawn by the caller for the whole batch)
                 nz, extra = ctx["inbox"]
                 idx = pred_ids[..., None].expand(-1, -1, P)

@@ -91,6 +91,7 @@ SIGNATURES = {
     "nova_modulate_rows": [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p],
     "nova_attn_fwd_lse": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_long, c_long, c_void_p],
     "nova_attn_bwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_void_p],
+    "nova_row_norm_bwd": [c_void_p] * 5 + [c_long, c_int, c_int, c_int] + [c_void_p] * 4 + [c_int, c_long, c_int, c_float, c_int, c_void_p],
     "nova_row_norm_chain": [c_void_p] * 5 + [c_long, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "nova_adaln_fc1": [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_long]
     + [c_int] * 4 + [c_void_p],
@@ -224,11 +225,15 @@ def gemm_fp8_bias_act(a8, a_scale, w8, w_scale, bias, act=0, out=None):
     return out
 
 
-def rope_table(pos, ids, pad, inv_freq, nb, hd):
-    """cos/sin table [nb, pad + n_tok, hd/2, 2] f32. pos [n_pos, 3] f32, ids [nb, n_tok] int64 or None."""
+def rope_table(pos, ids, pad, inv_freq, nb, hd, out=None):
+    """cos/sin table [nb, pad + n_tok, hd/2, 2] f32. pos [n_pos, 3] f32, ids [nb, n_tok] int64 or None.
+    `out`: a flat f32 buffer of at least that many elements (the hot loop's workspace slot); a view of it is returned."""
     n_pos = pos.shape[0]
     n_tok = ids.shape[1] if ids is not None else n_pos
-    out = torch.empty(nb, pad + n_tok, hd // 2, 2, dtype=torch.float32, device=pos.device)
+    if out is None:
+        out = torch.empty(nb, pad + n_tok, hd // 2, 2, dtype=torch.float32, device=pos.device)
+    else:
+        out = out[: nb * (pad + n_tok) * hd].view(nb, pad + n_tok, hd // 2, 2)
     call("nova_rope_table", ptr(pos, torch.float32), ptr(ids, torch.int64), ptr(out), nb, pad, n_tok, n_pos, hd,
          ptr(inv_freq, torch.float32), stream_ptr())
     return out

@@ -573,6 +573,35 @@ def test_fp8_gemm_mode_small_model(hip):
         NOVAPipeline(transformer=model.float(), scheduler=FlowMatchEulerDiscreteScheduler())(gemm_dtype="fp8", **kw)
 
 
+def test_ar_step_makes_no_engine_allocations(gold, hip):
+    """Hot-loop host hygiene: after warm-up an AR step of the engine runs entirely in workspace slots (ids, RoPE tables, the
+    last block's row temporaries, condition rows). Counted with the caching allocator's own statistics: the allocation
+    count of a K = 12 call minus that of a K = 6 call, per extra AR step, is what the CALLER's per-step noise draw costs
+    (the reference's semantics: one draw per step, transformer_3d.py:131) - at most 3 requests - and nothing else."""
+    order, noises = gold.t["out/order"][..., 0], gold.t["in/noises"]
+    nz = [noises[i % len(noises)] for i in range(16)]
+    pipe = NOVAPipeline(transformer=build_from_golden(gold, torch.bfloat16, "cuda"), scheduler=FlowMatchEulerDiscreteScheduler())
+    kw = dict(prompt_embeds=gold.prompt_embeds, num_diffusion_steps=gold.meta["S"], guidance_scale=gold.meta["guidance"],
+              output_type="latent", disable_progress_bar=True, pred_order=order, noise_fn=lambda i: nz[i].cuda(), lanes=1)
+
+    def allocs(K):
+        pipe(num_inference_steps=K, **kw)  # warm-up: workspace, graphs
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_stats()["allocation.all.allocated"]
+        x = pipe(num_inference_steps=K, **kw).frames
+        torch.cuda.synchronize()
+        n_steps = pipe.transformer.mask_embed.pred_pos  # all points generated
+        assert n_steps == order.shape[1] and torch.isfinite(x.float()).all()
+        return torch.cuda.memory_stats()["allocation.all.allocated"] - before
+
+    from diffnext.pipelines.nova.pipeline_nova import cosine_set_sizes
+
+    k6, k12 = (len([v for v in cosine_set_sizes(order.shape[1], K) if v > 0]) for K in (6, 12))
+    a6, a12 = allocs(6), allocs(12)
+    per_step = (a12 - a6) / (k12 - k6)
+    assert per_step <= 3.0, (a6, a12, k6, k12)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_decoder_graph_replay_equals_direct_launches(gold, hip, dtype):
     """nova_decoder_denoise captures its launch sequence per argument set and replays it as a hipGraph: the first call

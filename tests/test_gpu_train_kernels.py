@@ -171,3 +171,108 @@ def test_bench_launch_contract_one_rank_on_rccl(hip):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["steps"] == 1 and rec["value"] > 0 and rec["scaling"] == "weak"
     assert rec["config"]["global_batch"] == 8 and "roofline" in rec
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LayerNorm family backward (csrc/rownorm_bwd.hip) behind autograd.fused_norm, against PyTorch autograd in float32
+# ---------------------------------------------------------------------------------------------------------------------
+def _norm_ref(x, gamma, beta, scale, shift, gate, res, eps):
+    """The composition the modules spell out (vision_transformer.py:78-82, normalization.py:34-36, diffusion_mlp.py:52-53)."""
+    y = torch.nn.functional.layer_norm(x, (x.shape[-1],), gamma, beta, eps)
+    if scale is not None:
+        y = y * (1 + scale) + shift
+    if gate is not None:
+        y = y * gate
+    return y + res if res is not None else y
+
+
+NORM_KINDS = {  # which terms are present: the three uses in the model + the bare and the full combination
+    "vit_post_norm": dict(affine=True, ss=False, gate=False, res=True),
+    "adaln_modulate": dict(affine=False, ss=True, gate=False, res=False),
+    "gated_norm": dict(affine=True, ss=False, gate=True, res=True),
+    "plain": dict(affine=False, ss=False, gate=False, res=False),
+    "everything": dict(affine=True, ss=True, gate=True, res=True),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind", sorted(NORM_KINDS))
+@pytest.mark.parametrize("shape", [(3, 37, 128), (2, 300, 768), (5000, 1024), (1, 7, 1536)])
+def test_fused_norm_forward_backward_match_autograd(hip, dtype, kind, shape):
+    from nova_pointcloud_amd import autograd as A
+
+    k = NORM_KINDS[kind]
+    D = shape[-1]
+    g = torch.Generator().manual_seed(D + len(shape))
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dtype).cuda()
+    x, dy = r(*shape), r(*shape)
+    gamma = (1 + r(D, sc=0.2)).float() if k["affine"] else None
+    beta = r(D, sc=0.2).float() if k["affine"] else None
+    n_mod = (2 if k["ss"] else 0) + (1 if k["gate"] else 0)
+    mod = r(*shape[:-1], max(n_mod, 1) * D, sc=0.5)  # what `proj(SiLU(z))` yields; the terms are chunk views of it
+    res = r(*shape) if k["res"] else None
+    leaves = [t for t in (x, gamma, beta, mod if n_mod else None, res) if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    chunks = list(mod.chunk(max(n_mod, 1), dim=-1))
+    scale, shift = (chunks[0], chunks[1]) if k["ss"] else (None, None)
+    gate = chunks[-1] if k["gate"] else None
+    assert A.fused_norm_supported(x, gamma=gamma, scale=scale, shift=shift, gate=gate, res=res)
+    eps = 1e-6 if kind == "adaln_modulate" else 1e-5
+    out = A.fused_norm(x, gamma, beta, scale, shift, gate, res, eps)
+    out.backward(dy)
+    got = [t.grad.clone() for t in leaves]
+    # reference: the same values in float32 through PyTorch's own autograd
+    ref_leaves = [t.detach().float().requires_grad_(True) for t in leaves]
+    it = iter(ref_leaves)
+    xr = next(it)
+    gr, br = (next(it), next(it)) if k["affine"] else (None, None)
+    modr = next(it) if n_mod else mod.detach().float()
+    rc = list(modr.chunk(max(n_mod, 1), dim=-1))
+    ref = _norm_ref(xr, gr, br, rc[0] if k["ss"] else None, rc[1] if k["ss"] else None, rc[-1] if k["gate"] else None,
+                    next(it) if k["res"] else None, eps)
+    ref.backward(dy.float())
+    tol = {torch.float32: 2e-5, torch.bfloat16: 1.6e-2, torch.float16: 2e-3}[dtype]
+    assert out.shape == x.shape and out.dtype == dtype and _rel(out, ref.detach()) < tol
+    names = ["x"] + (["gamma", "beta"] if k["affine"] else []) + (["mod"] if n_mod else []) + (["res"] if k["res"] else [])
+    for name, gt, rl in zip(names, got, ref_leaves):
+        assert torch.isfinite(gt.float()).all(), name
+        # parameter gradients are sums over all rows of 16-bit-rounded terms: a few ulps of the storage type at the sum's scale
+        assert _rel(gt, rl.grad) < (4 * tol if name in ("gamma", "beta") else 2 * tol), (name, _rel(gt, rl.grad))
+
+
+def test_training_modules_take_the_fused_norm_and_match_the_torch_definition(hip):
+    """Block (post-norm residual x2), AdaLayerNormZero and DiffusionBlock with autograd on, on the GPU: the fused HIP norm is
+    what runs (call counter), and outputs + every parameter gradient match the same modules with it switched off."""
+    from diffnext.models.diffusion_mlp import DiffusionBlock
+    from diffnext.models.vision_transformer import Block
+    from nova_pointcloud_amd import autograd as A
+
+    torch.manual_seed(9)
+    for make, args in ((lambda: Block(256, 4), lambda: (torch.randn(2, 70, 256) * 0.7,)),
+                       (lambda: DiffusionBlock(256), lambda: (torch.randn(2, 70, 256) * 0.7, torch.randn(2, 70, 256) * 0.7))):
+        mod = make().cuda().float()
+        with torch.no_grad():
+            for p in mod.parameters():
+                p.add_(torch.randn_like(p) * 0.02)
+        ins = [t.cuda().requires_grad_(True) for t in args()]
+        before = A.stats["norm_calls"]
+        out = mod(*ins)
+        out.square().mean().backward()
+        assert A.stats["norm_calls"] > before
+        grads = {n: p.grad.clone() for n, p in mod.named_parameters()}
+        gin = [t.grad.clone() for t in ins]
+        mod.zero_grad()
+        for t in ins:
+            t.grad = None
+        A._NORM_ENABLED = False
+        try:
+            ref = mod(*ins)
+            ref.square().mean().backward()
+        finally:
+            A._NORM_ENABLED = True
+        assert _rel(out.detach(), ref.detach()) < 1e-4
+        for t, gi in zip(ins, gin):
+            assert _rel(gi, t.grad) < 1e-3
+        for n, p in mod.named_parameters():
+            assert _rel(grads[n], p.grad) < 1e-3, n

@@ -10,7 +10,7 @@ from nova_pointcloud_amd import hip  # noqa: E402
 from microbench import timeit  # noqa: E402
 
 libs = {}
-for path in sys.argv[1:3]:
+for path in sys.argv[1:]:
     lib = ctypes.CDLL(os.path.abspath(path))
     for name, argtypes in hip.SIGNATURES.items():
         if hasattr(lib, name):
