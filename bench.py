@@ -128,34 +128,38 @@ def cpu_baseline(pipe, width, heads, H, W, threads, with_config0=False):
     return rec
 
 
-PMC_KERNEL = {"attention": "attn_bf16_m16<bf16,2,false,true>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
+PMC_KERNEL_FP8 = {"attention": "attn_bf16_m16<bf16,96,2,false,true>", "gemm_bias": "gemm256p_kernel<fp8,0>", "gemm_bias_gelu": "gemm256p_kernel<fp8,5>",
+                  "qkv_gemm_rope": "gemm256p_kernel<fp8,3>"}
+PMC_KERNEL = {"attention": "attn_bf16_m16<bf16,64,2,false,true>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
               "qkv_gemm_rope": "gemm256p_kernel<bf16,3>"}
 
 
-def pmc_traffic(family, workload):
+def pmc_traffic(family, workload, fp8=False):
     """HBM bytes per launch of the dominant kernel from the newest profiles/r*_pmc.json (tools/pmc_collect.sh +
     tools/pmc_summary.py: separate rocprofv3 --pmc passes; counters cannot be read from inside the process). The file
     records the sha256 of the kernel sources it was measured on: a stale file is reported as such, not used."""
     import glob
     import hashlib
 
-    if workload != "d48w1024_2048pts_b32":
-        return None, "PMC passes are taken at the d48w1024 shapes only"
+    # bf16: one block at the d48w1024 shapes (profiles/r*_pmc.json); fp8 GEMM mode: one block at the d48w1536 shapes (r*_pmc_fp8.json)
+    if (workload, fp8) not in (("d48w1024_2048pts_b32", False), ("d48w1536_2048pts_b32", True)):
+        return None, "PMC passes are taken at the d48w1024 shapes (bf16) and the d48w1536 shapes (fp8 mode) only"
+    names, pattern = (PMC_KERNEL_FP8, "r*_pmc_fp8.json") if fp8 else (PMC_KERNEL, "r*_pmc.json")
     h = hashlib.sha256()
     csrc = os.path.join(PKG, "csrc")
     for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h"))):
         h.update(os.path.basename(path).encode())
         h.update(open(path, "rb").read())
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             doc = json.load(open(path))
-            rec = doc["kernels"][PMC_KERNEL[family]]
+            rec = doc["kernels"][names[family]]
         except (OSError, KeyError, ValueError):
             continue
         name = os.path.basename(path)
         if doc.get("source_sha256") != h.hexdigest():
             return None, f"profiles/{name} was measured on other kernel sources (sha mismatch): re-run tools/pmc_collect.sh"
-        return rec.get("hbm_bytes"), (f"profiles/{name}: {doc['shape']}; 2 x FETCH_SIZE + WRITE_SIZE of the {PMC_KERNEL[family]} launch, "
+        return rec.get("hbm_bytes"), (f"profiles/{name}: {doc['shape']}; 2 x FETCH_SIZE + WRITE_SIZE of the {names[family]} launch, "
                                       f"separate rocprofv3 --pmc passes")
     return None, "no profiles/r*_pmc.json"
 
@@ -306,12 +310,10 @@ def main():
         dom = max(mfma, key=lambda k: mfma[k]["ms"])
         # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be read from inside
         # the process); the committed summary is for the largest launch of that kernel, so it is reported with its context.
-        traffic, traffic_note = pmc_traffic(dom, args.workload)
+        traffic, traffic_note = pmc_traffic(dom, args.workload, fp8=args.dtype == "fp8")
         # fp8 mode: the fc1 (+GELU) and QKV (+RoPE) kernels are pure fp8 launches -> dense fp8 peak; attention is bf16; the
         # "gemm_bias" slot mixes the bf16 out-projection with the fp8 fc2 and is priced at the bf16 peak
         peak = MFMA_FP8_PEAK_TFLOPS if (args.dtype == "fp8" and dom in ("gemm_bias_gelu", "qkv_gemm_rope")) else MFMA_BF16_PEAK_TFLOPS
-        if args.dtype == "fp8":
-            traffic, traffic_note = None, "PMC passes are taken in bf16 mode"
         rec = {
             "metric": "generated points/sec/node, NOVA-d48w1024 @2048 pts, 64-step sample" if args.workload.startswith("d48w1024")
             else f"generated points/sec/node, {args.workload}",

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void attn_f32(const float* __restrict__ q, con
 // 1 / 2 = 16x16x32 with 32 / 64 query rows per wave (attn16.hip), 3 / 4 = the same with the row sums on the matrix pipe, 5 = 4 software-pipelined (P V of tile t-1 beside the exponentials of tile t); -1 = the shipped choice
 static thread_local int g_attn_variant = -1;
 int attn_set_variant(int v) {
-  if (v < -1 || v > 9) return -1;
+  if (v < -1 || v > 5) return -1;
   g_attn_variant = v;
   return 0;
 }
@@ -413,10 +413,13 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
     const float cl = q_prescaled ? 1.0f : c;
     const int rev = walk_is_reverse() ? 1 : 0;
     if (attn_variant() != 0) {
-      // 1 .. 5 as documented at attn_set_variant; 6 / 7 = 3 / 4 with static issue priorities by wave slot, 8 / 9 = 3 / 4 with a start stagger
-      const int av = attn_variant(), base = av <= 5 ? av : (av & 1) ? 4 : 3, dephase = av <= 5 ? 0 : av <= 7 ? 1 : 2;
-      return attn_fwd_m16(q, k, v, o, S, heads, Lq, Lk, hd, q_rs, kv_rs, o_rs, cl, dtype, st, kv_ss, lse, (base & 1) && base != 5 ? 32 : 64,
-                          base >= 3, base == 5, dephase);
+      // the shipped choice: 16x16x32 with the row sums on the matrix pipe; 64 query rows per wave where the 256-row workgroups
+      // tile the queries exactly and there are many of them (the full-length encoder blocks: +1.3 .. 2 % over 32 rows per wave
+      // at L = 2560, -5 .. 10 % at ragged or short L: profiles/r03_attn_variants_ab.txt). Depends on Lq only, never on the batch.
+      int av = attn_variant();
+      if (g_attn_variant < 0 && av == 3 && hd == 64 && Lq >= 2048 && Lq % 256 == 0) av = 4;
+      return attn_fwd_m16(q, k, v, o, S, heads, Lq, Lk, hd, q_rs, kv_rs, o_rs, cl, dtype, st, kv_ss, lse, (av & 1) && av != 5 ? 32 : 64, av >= 3,
+                          av == 5);
     }
     dispatch_half(dtype, [&](auto tag) {
       using E = decltype(tag);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
-  const int t = xcd_remap_dir(blockIdx.x, gridDim.x, (rev & 1) != 0);
+  const int t = xcd_remap_dir(blockIdx.x, gridDim.x, rev != 0);
   const int sh = t / nq, qt = t - sh * nq;
   const int head = sh % heads, s = sh / heads;
   const int q0 = qt * (4 * RW) + wid * RW;
@@ -267,22 +267,6 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
     }
   };
 
-  // De-phasing of the waves that share a SIMD (they come from different workgroups, start together and run the same loop at the
-  // same rate: in lockstep their matrix phases collide on the pipe and their vector phases on the issue port, and a tile
-  // costs the SUM of both - MI355X_MICROARCH 'Two waves per SIMD' item 9). mode 1: static issue priority by hardware wave slot
-  // (the higher slot wins every arbitration, so it runs ahead until the phases interleave); mode 2: the odd slots start half
-  // a tile late (slot k by k x 640 clocks).
-  const int dephase = (rev >> 1) & 3;
-  if (dephase) {
-    const int slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;  // HW_REG_HW_ID bits [3:0]: wave slot on this SIMD (low 2 bits)
-    if (dephase == 1) {
-      if (slot == 1) __builtin_amdgcn_s_setprio(1);
-      else if (slot == 2) __builtin_amdgcn_s_setprio(2);
-      else if (slot == 3) __builtin_amdgcn_s_setprio(3);
-    } else {
-      for (int z = 0; z < slot; ++z) __builtin_amdgcn_s_sleep(10);  // slot x 640 clocks (a tile step is ~2-4 k clocks)
-    }
-  }
   stage(0, nkt - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces (asm: not counted by the compiler)
   __syncthreads();
@@ -568,12 +552,12 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const E* __restrict__ q
 
 // rows_per_wave 32 or 64 (head_dim 64; head_dim 96 runs the 32-row form with MFMA row sums whatever is asked); dtype NOVA_BF16 or NOVA_F16 (attn_fwd in attn.hip checks shapes and strides before it dispatches here)
 int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd, long q_rs, long kv_rs,
-                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined, int dephase) {
+                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined) {
   const int rw = (rows_per_wave == 64 && hd == 64) ? 64 : 32;
   const int nq = (Lq + 4 * rw - 1) / (4 * rw);
   if ((long)nq * heads * S > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
   dim3 block(256), grid((unsigned)((long)nq * heads * S));
-  const int rev = (walk_is_reverse() ? 1 : 0) | (dephase << 1);
+  const int rev = walk_is_reverse() ? 1 : 0;
   dispatch_half(dtype, [&](auto tag) {
     using E = decltype(tag);
     const E *qq = (const E*)q, *kk = (const E*)k, *vv = (const E*)v;

@@ -578,7 +578,7 @@ template <typename T> static void key_put(std::string& k, const T& v) { k.append
 extern "C" {
 
 int nova_debug_set_attn_variant(int variant) {
-  NOVA_REQUIRE(attn_set_variant(variant) == 0, NOVA_ERR_ARG, "nova_debug_set_attn_variant: %d is not one of -1 .. 9", variant);
+  NOVA_REQUIRE(attn_set_variant(variant) == 0, NOVA_ERR_ARG, "nova_debug_set_attn_variant: %d is not one of -1 .. 5", variant);
   return 0;
 }
 

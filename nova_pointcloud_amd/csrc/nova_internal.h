@@ -56,9 +56,11 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
              bool q_prescaled = false, long kv_seq_stride = 0, float* lse = nullptr);
 // attn16.hip: the same attention on the 16x16x32 MFMA shape (bf16, head_dim 64), 32 or 64 query rows per wave
 int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd, long q_rs, long kv_rs,
-                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined = false, int dephase = 0);
-constexpr int NOVA_ATTN_DEFAULT_VARIANT = 3;  // 16x16x32, 32 rows per wave, row sums on the matrix pipe: +8..11 % over variant 0 at every L measured (profiles/r03_attn_variants.txt)
-int attn_set_variant(int v);  // -1 default, 0 .. 9 (attn.hip); -1 returned for other values
+                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined = false);
+// 16x16x32, 32 rows per wave, row sums on the matrix pipe: +8 .. 11 % over variant 0 at every L measured (profiles/r03_attn_variants_ab.txt);
+// attn_fwd takes variant 4 (64 rows per wave) where its 256-row workgroups tile Lq exactly
+constexpr int NOVA_ATTN_DEFAULT_VARIANT = 3;
+int attn_set_variant(int v);  // -1 default, 0 .. 5 (attn.hip); -1 returned for other values
 int attn_variant();
 // attn_bwd.hip (bf16, head_dim 64 / 96): gradients of the attention above from q (pre-scaled by scale * log2 e), k, v, the
 // forward's output o and log2-domain row log-sum-exp, and dO; delta [S, heads, L] is scratch (filled with sum_c dO * O first).

@@ -39,7 +39,7 @@ def source_hash():
 
 def short(name):
     m = re.match(r"(?:void )?(?:nova::)?([A-Za-z0-9_]+)(<[^(]*>)?", name)
-    tmpl = (m.group(2) or "").replace("unsigned short", "bf16").replace(" ", "")
+    tmpl = (m.group(2) or "").replace("unsigned short", "bf16").replace("unsigned char", "fp8").replace("nova::f16_t", "f16").replace(" ", "")
     return m.group(1) + tmpl
 
 
@@ -81,13 +81,21 @@ ALGO = {
 
 def algo_for(k):
     if k.startswith("attn_"):
-        return ALGO["attn"]
+        return ALGO.get("attn")
     if k.startswith("row_norm"):
-        return ALGO["row_norm"]
+        return ALGO.get("row_norm")
     return ALGO.get(k)
 
 
 def main():
+    args = list(sys.argv[1:])
+    shape = "one ViT block, S=64 x L=2560, D=1024, 16 heads, bf16 (tools/pmc_kernels.py)"
+    if "--shape" in args:  # another driver / shape: no algorithmic-byte columns (they are written for the standard shape)
+        i = args.index("--shape")
+        shape = args[i + 1]
+        del args[i:i + 2]
+        ALGO.clear()
+    sys.argv = [sys.argv[0]] + args
     root, out_path = sys.argv[1], sys.argv[2]
     acc, dur = counters(root), durations(root)
     kernels = {}
@@ -127,7 +135,7 @@ def main():
             rec.update(operand_bytes=al[0], out_bytes=al[1], fetch_over_operands=round(rec["fetch_bytes"] / al[0], 2),
                        hbm_over_algorithmic=round(rec["hbm_bytes"] / (al[0] + al[1]), 2))
         kernels[k] = rec
-    doc = {"source_sha256": source_hash(), "shape": "one ViT block, S=64 x L=2560, D=1024, 16 heads, bf16 (tools/pmc_kernels.py)",
+    doc = {"source_sha256": source_hash(), "shape": shape,
            "units": __doc__.split("Per kernel")[1].strip(), "kernels": kernels}
     with open(out_path, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)
