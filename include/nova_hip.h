@@ -69,10 +69,13 @@ int nova_debug_force_gemm_tile(int tile);
 int nova_debug_set_attn_variant(int variant);
 
 /* nova_decoder_denoise replays its launch sequence as a hipGraph, captured once per distinct argument set (on by
- * default; environment NOVA_GRAPHS=0 or on = 0 here switches to direct launches and drops the cached graphs of the
- * calling thread). Results are identical either way. Stats: graphs captured / replayed by the calling thread. */
+ * default; environment NOVA_GRAPHS=0 or on = 0 here switches to direct launches for every thread and drops the cached graphs -
+ * the calling thread's at once, every other thread's at its next nova_decoder_denoise). Results are identical either way. Stats: graphs captured / replayed by the calling thread. */
 int nova_debug_set_graphs(int on);
 int nova_debug_graph_stats(long* captures, long* replays);
+/* Drops the calling thread's cached graphs (a caller that re-allocates the workspaces it passes to nova_decoder_denoise: graphs keyed
+ * by the old addresses can never be replayed and would only pile up until the 2048-entry cap). */
+int nova_debug_drop_graphs(void);
 
 /* ---- projection GEMM -----------------------------------------------------------------------
  * out[M,N] = act(A[M,K] * W[N,K]^T + bias[N])        W in nn.Linear layout.
@@ -130,13 +133,17 @@ int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, i
  * lse[s, head, l] = log2 sum_j 2^(q~_l . k_j), the backward rebuilds P from it (flash-style, nothing of size L x L is
  * stored) and returns the gradients w.r.t. the UNSCALED q, k and v; it needs the forward's o for delta[s, head, l] =
  * sum_c dO * O, which it writes into delta_scratch [S, heads, L] f32 first. All matrices token-major with row strides
- * as above. Replaces the autograd of F.scaled_dot_product_attention at vision_transformer.py:63 inside the training
- * forward (transformer_3d.py:79-100). */
+ * as above. key_limit (NULL = no mask): int32 [L], non-decreasing, >= 1 - query l attends to keys [0, key_limit[l]); this is the
+ * reference's block-causal frame mask of multi-frame training (`MaskEmbed.get_attn_mask`, embeddings.py:247-260, set on the
+ * video encoder's blocks at transformer_3d.py:176-177: a token sees the tokens of frames <= its own, the prefix counting as
+ * frame 0), passed as the end of each token's visible range instead of an L x L matrix. Replaces the autograd of
+ * F.scaled_dot_product_attention at vision_transformer.py:63 inside the training forward (transformer_3d.py:79-100). */
 int nova_attn_fwd_lse(const void* q_scaled, const void* k, const void* v, void* o, float* lse, int S, int heads, int L,
-                      int head_dim, long qkv_row_stride, long o_row_stride, void* stream);
+                      int head_dim, long qkv_row_stride, long o_row_stride, const int* key_limit, void* stream);
 int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                   float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, int head_dim,
-                  long qkv_row_stride, long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream);
+                  long qkv_row_stride, long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale,
+                  const int* key_limit, void* stream);
 
 /* ---- training: backward of the LayerNorm family --------------------------------------------------------------------
  * For y = LN(x; eps) [* gamma + beta] [* (1 + scale) + shift] [* gate] [+ res] (nova_row_norm's forward) and the output

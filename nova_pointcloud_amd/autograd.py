@@ -1,6 +1,7 @@
 """torch.autograd bindings of the training kernels of libnova_hip.so.
 
-`attention(q, k, v)` is F.scaled_dot_product_attention (no mask, no dropout) for bf16 device tensors with head_dim 64 / 96:
+`attention(q, k, v, attn_mask)` is F.scaled_dot_product_attention (no dropout; no mask, or the block-causal frame mask of multi-frame
+training passed as a per-query key limit) for bf16 device tensors with head_dim 64 / 96:
 forward on `attn_bf16` with the row log-sum-exp kept, backward on `attn_bwd_dq` / `attn_bwd_dkv` (csrc/attn_bwd.hip;
 reference vision_transformer.py:63 under the training forward transformer_3d.py:79-100).
 
@@ -22,13 +23,44 @@ LOG2E = 1.4426950408889634
 stats = {"attention_calls": 0}  # forward calls of the HIP attention in this process (launch tests and logs read it)
 
 
+_KEY_LIMITS = {}  # id(mask tensor) -> (version, key_limit or None): the O(L^2) structure check runs once per mask
+
+
+def key_limit_of_mask(attn_mask):
+    """int32 [L] `key_limit` with mask[i, j] visible <=> j < key_limit[i] when the [L, L] mask (additive 0 / -inf as the reference builds
+    it, embeddings.py:247-260, or boolean) has that form with non-decreasing limits >= 1 - the block-causal frame mask - else None."""
+    if attn_mask is None or attn_mask.dim() != 2 or attn_mask.shape[0] != attn_mask.shape[1] or not attn_mask.is_cuda:
+        return None
+    hit = _KEY_LIMITS.get(id(attn_mask))
+    if hit is not None and hit[0] == attn_mask._version and hit[2]() is attn_mask:
+        return hit[1]
+    import weakref
+
+    L = attn_mask.shape[0]
+    allowed = attn_mask if attn_mask.dtype == torch.bool else attn_mask > float("-inf")
+    if attn_mask.dtype != torch.bool and not bool(((attn_mask == 0) | ~allowed).all()):
+        limit = None  # finite non-zero biases: not a pure visibility mask
+    else:
+        limit = allowed.sum(-1).to(torch.int32)
+        prefix = torch.arange(L, device=attn_mask.device)[None, :] < limit[:, None]
+        ok = bool(torch.equal(prefix, allowed)) and bool((limit >= 1).all()) and bool((limit[1:] >= limit[:-1]).all())
+        limit = limit.contiguous() if ok else None
+    if len(_KEY_LIMITS) > 64:
+        _KEY_LIMITS.clear()
+    _KEY_LIMITS[id(attn_mask)] = (attn_mask._version, limit, weakref.ref(attn_mask))
+    return limit
+
+
 def attention_supported(q, attn_mask=None):
-    return (_ENABLED and q.is_cuda and q.dtype == torch.bfloat16 and q.shape[-1] in (64, 96) and attn_mask is None and q.dim() == 4)
+    """bf16 device tensors [S, heads, L, 64 | 96]; no mask, or a mask of the per-query key-limit form (key_limit_of_mask)."""
+    if not (_ENABLED and q.is_cuda and q.dtype == torch.bfloat16 and q.shape[-1] in (64, 96) and q.dim() == 4):
+        return False
+    return attn_mask is None or (attn_mask.shape[-1] == q.shape[-2] and key_limit_of_mask(attn_mask) is not None)
 
 
 class NovaAttentionFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v):
+    def forward(ctx, q, k, v, key_limit=None):
         S, h, L, d = q.shape
         if k.shape != q.shape or v.shape != q.shape:
             raise ValueError("nova attention (training) is self-attention: q, k, v must share one shape [S, heads, L, head_dim]")
@@ -41,27 +73,33 @@ class NovaAttentionFunction(torch.autograd.Function):
         o = torch.empty(S, L, h, d, dtype=torch.bfloat16, device=q.device)
         lse = torch.empty(S, h, L, dtype=torch.float32, device=q.device)
         hip.call("nova_attn_fwd_lse", qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), o.data_ptr(), lse.data_ptr(), S, h, L, d, h * d, h * d,
-                 hip.stream_ptr())
-        ctx.save_for_backward(qt, kt, vt, o, lse)
+                 hip.ptr(key_limit), hip.stream_ptr())
+        ctx.save_for_backward(qt, kt, vt, o, lse, key_limit)
         ctx.scale = scale
         return o.transpose(1, 2)
 
     @staticmethod
     def backward(ctx, d_out):
-        qt, kt, vt, o, lse = ctx.saved_tensors
+        qt, kt, vt, o, lse, key_limit = ctx.saved_tensors
         S, L, h, d = qt.shape
         do = d_out.transpose(1, 2).to(torch.bfloat16).contiguous()
         delta = torch.empty(S, h, L, dtype=torch.float32, device=do.device)  # filled by the library: sum_c dO * O
         dq, dk, dv = torch.empty_like(qt), torch.empty_like(kt), torch.empty_like(vt)
         hip.call("nova_attn_bwd", qt.data_ptr(), kt.data_ptr(), vt.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
                  delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), S, h, L, d, h * d, h * d, h * d, h * d, ctx.scale,
-                 hip.stream_ptr())
-        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2)
+                 hip.ptr(key_limit), hip.stream_ptr())
+        return dq.transpose(1, 2), dk.transpose(1, 2), dv.transpose(1, 2), None
 
 
-def attention(q, k, v):
-    """softmax(q k^T / sqrt(d)) v for [S, heads, L, 64 | 96] bf16 device tensors, differentiable."""
-    return NovaAttentionFunction.apply(q, k, v)
+def attention(q, k, v, attn_mask=None):
+    """softmax(q k^T / sqrt(d) [+ mask]) v for [S, heads, L, 64 | 96] bf16 device tensors, differentiable. `attn_mask`: None or an
+    [L, L] visibility mask of the per-query key-limit form (the block-causal frame mask of multi-frame training)."""
+    limit = None
+    if attn_mask is not None:
+        limit = key_limit_of_mask(attn_mask)
+        if limit is None:
+            raise ValueError("nova attention: the mask is not of the per-query key-limit form (check attention_supported first)")
+    return NovaAttentionFunction.apply(q, k, v, limit)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

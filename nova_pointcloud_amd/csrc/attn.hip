@@ -395,10 +395,12 @@ int attn_set_variant(int v) {
 int attn_variant() { return g_attn_variant < 0 ? NOVA_ATTN_DEFAULT_VARIANT : g_attn_variant; }
 
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
-             long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st, bool q_prescaled, long kv_ss, float* lse) {
+             long q_rs, long kv_rs, long o_rs, float scale, int dtype, hipStream_t st, bool q_prescaled, long kv_ss, float* lse,
+             const int* klim) {
   if (S <= 0 || Lq <= 0) return 0;
   if (hd != 64 && hd != 96) return set_error(NOVA_ERR_SHAPE, "attn_fwd: head_dim %d not built (have 64 and 96)", hd);
   if (Lk <= 0 || heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_fwd: bad Lk/heads");
+  if (klim && (!lse || !dtype_is16(dtype) || Lq != Lk)) return set_error(NOVA_ERR_ARG, "attn_fwd: a key-limit mask comes with the 16-bit training forward (Lq == Lk, log-sum-exp output)");
   if (lse && !dtype_is16(dtype)) return set_error(NOVA_ERR_ARG, "attn_fwd: the log-sum-exp output is built for the 16-bit kernels");
   const int align = dtype_is16(dtype) ? 8 : 4;  // 16-byte row alignment for the vector loads
   if (q_rs % align || kv_rs % align || o_rs % align) return set_error(NOVA_ERR_SHAPE, "attn_fwd: row strides must be 16-byte multiples");
@@ -412,6 +414,7 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
   if (dtype_is16(dtype)) {
     const float cl = q_prescaled ? 1.0f : c;
     const int rev = walk_is_reverse() ? 1 : 0;
+    if (klim) return attn_fwd_m16(q, k, v, o, S, heads, Lq, Lk, hd, q_rs, kv_rs, o_rs, cl, dtype, st, kv_ss, lse, 32, true, false, klim);
     if (attn_variant() != 0) {
       // the shipped choice: 16x16x32 with the row sums on the matrix pipe; 64 query rows per wave where the 256-row workgroups
       // tile the queries exactly and there are many of them (the full-length encoder blocks: +1.3 .. 2 % over 32 rows per wave

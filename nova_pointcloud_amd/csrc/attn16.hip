@@ -59,11 +59,17 @@ __device__ __forceinline__ float sum_over_g(float x) {
 
 // HD = 96 (d48w1536): a 64-wide image plus a 32-wide image (64-byte rows) per K / V tile, as attn.hip, so every LDS-DMA piece
 // stays row aligned; their swizzles: K32 chunk ^ s((row >> 2) & 3), s = (0, 2, 3, 1); V32 chunk ^ (((row >> 2) & 1) << 1).
-template <typename E, int HD, int NQB, bool LSE, bool SUMM>  // E: bf16_t / f16_t (same loads, LDS images and stores; MFMA form and pair packing differ)
+// MASK (the training forward of multi-frame models): a per-query key limit klim[Lq] - query i attends to keys [0, klim[i]), klim
+// non-decreasing and >= 1 - which is what the reference's block-causal frame mask is (embeddings.py:247-260: token i sees the tokens
+// of frames <= its own; the prefix counts as frame 0). Tiles are then walked in natural order (tile 0 holds an allowed key for
+// every row, so the first step's max is finite), every tile applies the limit, and tiles past the workgroup's largest limit are
+// never staged.
+template <typename E, int HD, int NQB, bool LSE, bool SUMM, bool MASK = false>  // E: bf16_t / f16_t (same loads, LDS images and stores; MFMA form and pair packing differ)
 __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16_m16(const E* __restrict__ q, const E* __restrict__ k,
                                                                          const E* __restrict__ v, E* __restrict__ o,
                                                                          int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
-                                                                         int heads, int nq, int rev, long kv_ss, float* __restrict__ lse) {
+                                                                         int heads, int nq, int rev, long kv_ss, float* __restrict__ lse,
+                                                                         const int* __restrict__ klim = nullptr) {
   constexpr int NDS = HD / 32, NDVB = HD / 16, RW = 16 * NQB;
   constexpr int B_T32 = B_KV * 64;                                  // 32-wide image (HD = 96): 4 KiB
   constexpr int BUF = 2 * B_T + (HD == 96 ? 2 * B_T32 : 0);         // [K64 | V64 | K32 | V32]
@@ -165,11 +171,18 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
                         : vrow * 64u + ((((uint32_t)(2 * (dvb - 4) + (t_p >> 1))) ^ (((vrow >> 2) & 1u) << 1)) << 4) + 8u * (t_p & 1);
   const uint32_t koff2 = (uint32_t)i * 64u + (((uint32_t)g ^ (uint32_t)((0x78 >> (2 * ((i >> 2) & 3))) & 3)) << 4);  // d-step 2: the 32-wide K image
 
-  const int nkt = (Lk + B_KV - 1) / B_KV;
+  int kl[NQB];  // MASK: this lane's key limit per query block
+  int k_end = Lk;
+  if constexpr (MASK) {
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) kl[qb] = min(klim[min(q0 + 16 * qb + i, Lq - 1)], Lk);
+    k_end = min(klim[min(qt * (4 * RW) + 4 * RW - 1, Lq - 1)], Lk);  // the workgroup's last row has its largest limit
+  }
+  const int nkt = (k_end + B_KV - 1) / B_KV;
   // Tile order: the (possibly ragged) LAST tile goes first, as a peeled step (softmax does not care about key order), so the
   // steady-state loop carries neither masking code nor the first-tile case, and the compiler is free to run the lane-local
   // max chains under the score MFMAs: step 0 <-> tile nkt - 1, step j >= 1 <-> tile j - 1; K/V of step j in buffer j & 1.
-  auto step = [&](auto first, int buf) {
+  auto step = [&](auto first, int buf, int tile) {
     constexpr bool FIRST = decltype(first)::value;
     const char* tk = smem + buf * BUF;
     const char* tv = tk + B_T;
@@ -188,13 +201,22 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
           st[qb][kb] = Half16<E>::mfma16(kf, qf[qb][ds], ds == 0 ? negm[qb] : st[qb][kb]);
       }
     }
-    if constexpr (FIRST) {
+    if constexpr (MASK) {  // every tile: keys at or past the query's limit (which is <= Lk) contribute nothing
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = tile * B_KV + 16 * kb + 4 * g + r;
+#pragma unroll
+          for (int qb = 0; qb < NQB; ++qb) st[qb][kb][r] = key < kl[qb] ? st[qb][kb][r] : NEG_INF16;
+        }
+    } else if constexpr (FIRST) {
       if ((Lk & (B_KV - 1)) != 0) {  // ragged tile: keys >= Lk contribute nothing
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = (nkt - 1) * B_KV + 16 * kb + 4 * g + r;
+            const int key = tile * B_KV + 16 * kb + 4 * g + r;
             if (key >= Lk) {
 #pragma unroll
               for (int qb = 0; qb < NQB; ++qb) st[qb][kb][r] = NEG_INF16;
@@ -267,16 +289,17 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
     }
   };
 
-  stage(0, nkt - 1);
+  auto tile_of = [&](int j) { return MASK ? j : (j == 0 ? nkt - 1 : j - 1); };
+  stage(0, tile_of(0));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA pieces (asm: not counted by the compiler)
   __syncthreads();
-  if (nkt > 1) stage(1, 0);
-  step(std::true_type{}, 0);
+  if (nkt > 1) stage(1, tile_of(1));
+  step(std::true_type{}, 0, tile_of(0));
   for (int j = 1; j < nkt; ++j) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (j + 1 < nkt) stage((j + 1) & 1, j);
-    step(std::false_type{}, j & 1);
+    if (j + 1 < nkt) stage((j + 1) & 1, tile_of(j + 1));
+    step(std::false_type{}, j & 1, tile_of(j));
   }
 
   // ---- finalize: lane (i, g) holds O[q0 + 16 qb + i][16 dvb + 4 g + 0..3]
@@ -552,7 +575,21 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const E* __restrict__ q
 
 // rows_per_wave 32 or 64 (head_dim 64; head_dim 96 runs the 32-row form with MFMA row sums whatever is asked); dtype NOVA_BF16 or NOVA_F16 (attn_fwd in attn.hip checks shapes and strides before it dispatches here)
 int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd, long q_rs, long kv_rs,
-                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined) {
+                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined,
+                 const int* klim) {
+  if (klim) {  // the masked training forward: built in the shipped form with the log-sum-exp output
+    if (!lse) return set_error(NOVA_ERR_ARG, "attn_fwd: a key-limit mask comes with the training forward (log-sum-exp output)");
+    const int nqm = (Lq + 127) / 128;
+    dim3 blk(256), grd((unsigned)((long)nqm * heads * S));
+    const int rv = walk_is_reverse() ? 1 : 0;
+    dispatch_half(dtype, [&](auto tag) {
+      using E = decltype(tag);
+      if (hd == 64) hipLaunchKernelGGL((attn_bf16_m16<E, 64, 2, true, true, true>), grd, blk, 0, st, (const E*)q, (const E*)k, (const E*)v, (E*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nqm, rv, kv_ss, lse, klim);
+      else hipLaunchKernelGGL((attn_bf16_m16<E, 96, 2, true, true, true>), grd, blk, 0, st, (const E*)q, (const E*)k, (const E*)v, (E*)o, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nqm, rv, kv_ss, lse, klim);
+      return 0;
+    });
+    return check_launch("attn_fwd_m16 (masked)");
+  }
   const int rw = (rows_per_wave == 64 && hd == 64) ? 64 : 32;
   const int nq = (Lq + 4 * rw - 1) / (4 * rw);
   if ((long)nq * heads * S > 0x7fffffffL) return set_error(NOVA_ERR_SHAPE, "attn_fwd: grid too large");
@@ -564,7 +601,7 @@ int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, in
     E* oo = (E*)o;
 #define NOVA_A16(NQB_, SUMM_)                                                                                                       \
   do {                                                                                                                             \
-    if (lse) hipLaunchKernelGGL((attn_bf16_m16<E, 64, NQB_, true, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse); \
+    if (lse) hipLaunchKernelGGL((attn_bf16_m16<E, 64, NQB_, true, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse, nullptr); \
     else hipLaunchKernelGGL((attn_bf16_m16<E, 64, NQB_, false, SUMM_>), grid, block, 0, st, qq, kk, vv, oo, Lq, Lk, q_rs, kv_rs, o_rs, cl, heads, nq, rev, kv_ss, lse);    \
   } while (0)
     if (hd == 96) {  // built in the shipped form only: 32 rows per wave, row sums on the matrix pipe

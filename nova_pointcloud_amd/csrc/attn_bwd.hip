@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
                                                       const bf16_t* __restrict__ v, const bf16_t* __restrict__ d_o,
                                                       const float* __restrict__ lse, const float* __restrict__ delta,
                                                       bf16_t* __restrict__ dq, int L, long qkv_rs, long do_rs, long dq_rs,
-                                                      float scale, int heads, int nq) {
+                                                      float scale, int heads, int nq, const int* __restrict__ klim) {
   constexpr int NKS = HD / 16, NDB = HD / 32, TILE = tile_bytes<HD>();
   constexpr int BUF = 2 * TILE;  // [K | V]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -137,6 +137,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
   }
   const float lse_q = lse[((size_t)s * heads + head) * L + qrow];
   const float del_q = delta[((size_t)s * heads + head) * L + qrow];
+  // key limit of the lane's query (block-causal frame mask of multi-frame training: keys [0, klim[q]) are visible, klim
+  // non-decreasing - attn16.hip MASK); without a mask every key below L
+  const int kl_q = klim ? min(klim[qrow], L) : L;
+  const int k_end = klim ? min(klim[min(qt * 128 + 127, L - 1)], L) : L;  // the workgroup's last row sees the most keys
 
   const char* kb_ = reinterpret_cast<const char*>(k + (size_t)s * L * qkv_rs + head * HD);
   const char* vb_ = reinterpret_cast<const char*>(v + (size_t)s * L * qkv_rs + head * HD);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
   f16v dqt[NDB];  // dQ^T [d x q] in 32-row d blocks
 #pragma unroll
   for (int db = 0; db < NDB; ++db) dqt[db] = zero16();
-  const int nkt = (L + B_T - 1) / B_T;
+  const int nkt = (k_end + B_T - 1) / B_T;
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq(const bf16_t* __restrict__
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int key = kt * B_T + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const float p = key < L ? __builtin_amdgcn_exp2f(st[i] - lse_q) : 0.f;
+        const float p = key < kl_q ? __builtin_amdgcn_exp2f(st[i] - lse_q) : 0.f;
         st[i] = p * (dpt[i] - del_q);  // dS^T
       }
       pack_acc(st, dsb[kb]);
@@ -206,9 +210,9 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv(const bf16
                                                        const bf16_t* __restrict__ v, const bf16_t* __restrict__ d_o,
                                                        const float* __restrict__ lse, const float* __restrict__ delta,
                                                        bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int L, long qkv_rs,
-                                                       long do_rs, long dkv_rs, int heads, int nk) {
+                                                       long do_rs, long dkv_rs, int heads, int nk, const int* __restrict__ klim) {
   constexpr int NKS = HD / 16, NDB = HD / 32, TILE = tile_bytes<HD>();
-  constexpr int BUF = 2 * TILE + 2 * B_T * 4;  // [Q | dO | lse | delta]
+  constexpr int BUF = 2 * TILE + 3 * B_T * 4;  // [Q | dO | lse | delta | key limit]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,10 +242,11 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv(const bf16
     char* b = smem + buf * BUF;
     stage_rows<HD>(qb_, qB, qt * B_T, L - 1, b, wid, lane);
     stage_rows<HD>(ob_, oB, qt * B_T, L - 1, b + TILE, wid, lane);
-    if (tid < 2 * B_T) {  // the tile's lse | delta (plain stores: visible after the barrier that opens the tile)
+    if (tid < 3 * B_T) {  // the tile's lse | delta | key limit (plain stores: visible after the barrier that opens the tile)
       const int i = tid & (B_T - 1);
       const int row = min(qt * B_T + i, L - 1);
-      reinterpret_cast<float*>(b + 2 * TILE)[tid] = tid < B_T ? lse_b[row] : del_b[row];
+      if (tid < 2 * B_T) reinterpret_cast<float*>(b + 2 * TILE)[tid] = tid < B_T ? lse_b[row] : del_b[row];
+      else reinterpret_cast<int*>(b + 2 * TILE)[tid] = (qt * B_T + i) >= L ? 0 : (klim ? klim[row] : L);  // queries past L see no key
     }
   };
 
@@ -249,14 +254,23 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv(const bf16
 #pragma unroll
   for (int db = 0; db < NDB; ++db) dkt[db] = dvt[db] = zero16();
   const int nqt = (L + B_T - 1) / B_T;
-  stage(0, 0);
-  for (int qt = 0; qt < nqt; ++qt) {
+  // masked: query tiles whose largest limit does not reach this workgroup's first key contribute nothing (klim is non-decreasing,
+  // so they form a prefix of the tile list)
+  int qt_first = 0;
+  if (klim) {
+    const int key_first = kt0 * 128;
+    while (qt_first < nqt - 1 && klim[min(qt_first * B_T + B_T - 1, L - 1)] <= key_first) ++qt_first;
+  }
+  const int key_lane = k0 + r;  // the lane's key
+  stage(qt_first & 1, qt_first);
+  for (int qt = qt_first; qt < nqt; ++qt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (qt + 1 < nqt) stage((qt + 1) & 1, qt + 1);
     const char* tq = smem + (qt & 1) * BUF;
     const char* to = tq + TILE;
     const float* tl = reinterpret_cast<const float*>(tq + 2 * TILE);
+    const int* tkl = reinterpret_cast<const int*>(tq + 2 * TILE) + 2 * B_T;
     bf8v pb[2][2], dsb[2][2];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -271,9 +285,10 @@ __global__ __launch_bounds__(256, HD == 64 ? 2 : 1) void attn_bwd_dkv(const bf16
       for (int g = 0; g < 4; ++g) {  // accumulator rows 4 g .. 4 g + 3 are queries 32 qb + 8 g + 4 hh + 0..3
         const int qi = qb * 32 + 8 * g + 4 * hh;
         const f4v l4 = *reinterpret_cast<const f4v*>(tl + qi), d4 = *reinterpret_cast<const f4v*>(tl + B_T + qi);
+        const auto k4 = *reinterpret_cast<const __attribute__((ext_vector_type(4))) int*>(tkl + qi);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = (qt * B_T + qi + e) < L ? __builtin_amdgcn_exp2f(sa[4 * g + e] - l4[e]) : 0.f;
+          const float p = key_lane < k4[e] ? __builtin_amdgcn_exp2f(sa[4 * g + e] - l4[e]) : 0.f;
           sa[4 * g + e] = p;
           dpa[4 * g + e] = p * (dpa[4 * g + e] - d4[e]);  // dS
         }
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 
 int attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, void* dq,
              void* dk, void* dv, int S, int heads, int L, int hd, long qkv_rs, long o_rs, long do_rs, long dqkv_rs, float scale,
-             hipStream_t st) {
+             hipStream_t st, const int* klim) {
   if (S <= 0 || L <= 0) return 0;
   if (heads <= 0) return set_error(NOVA_ERR_SHAPE, "attn_bwd: bad heads");
   if (hd != 64 && hd != 96) return set_error(NOVA_ERR_SHAPE, "attn_bwd: head_dim %d not built (have 64 and 96)", hd);
@@ -354,13 +369,13 @@ int attn_bwd(const void* q, const void* k, const void* v, const void* o, const v
                      do_rs, o_rs, rows);
   const dim3 grid((unsigned)blocks), block(256);
   if (hd == 64) {
-    hipLaunchKernelGGL(attn_bwd_dq<64>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dq, L, qkv_rs, do_rs, dqkv_rs, scale, heads, nt);
+    hipLaunchKernelGGL(attn_bwd_dq<64>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dq, L, qkv_rs, do_rs, dqkv_rs, scale, heads, nt, klim);
     hipLaunchKernelGGL(attn_bwd_dkv<64>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dk, (bf16_t*)dv, L, qkv_rs, do_rs, dqkv_rs,
-                       heads, nt);
+                       heads, nt, klim);
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq<96>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dq, L, qkv_rs, do_rs, dqkv_rs, scale, heads, nt);
+    hipLaunchKernelGGL(attn_bwd_dq<96>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dq, L, qkv_rs, do_rs, dqkv_rs, scale, heads, nt, klim);
     hipLaunchKernelGGL(attn_bwd_dkv<96>, grid, block, 0, st, qq, kk, vv, oo, lse, delta, (bf16_t*)dk, (bf16_t*)dv, L, qkv_rs, do_rs, dqkv_rs,
-                       heads, nt);
+                       heads, nt, klim);
   }
   return check_launch("attn_bwd");
 }

@@ -187,18 +187,19 @@ int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, i
 }
 
 int nova_attn_fwd_lse(const void* q_scaled, const void* k, const void* v, void* o, float* lse, int S, int heads, int L,
-                      int head_dim, long qkv_row_stride, long o_row_stride, void* stream) {
+                      int head_dim, long qkv_row_stride, long o_row_stride, const int* key_limit, void* stream) {
   NOVA_REQUIRE(q_scaled && k && v && o && lse, NOVA_ERR_ARG, "attn_fwd_lse: null pointer");
   return attn_fwd(q_scaled, k, v, o, S, heads, L, L, head_dim, qkv_row_stride, qkv_row_stride, o_row_stride, 1.0f, NOVA_BF16,
-                  (hipStream_t)stream, true, 0, lse);
+                  (hipStream_t)stream, true, 0, lse, key_limit);
 }
 
 int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void* o, const void* d_o, const float* lse,
                   float* delta_scratch, void* dq, void* dk, void* dv, int S, int heads, int L, int head_dim,
-                  long qkv_row_stride, long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale, void* stream) {
+                  long qkv_row_stride, long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale,
+                  const int* key_limit, void* stream) {
   NOVA_REQUIRE(q_scaled && k && v && o && d_o && lse && delta_scratch && dq && dk && dv, NOVA_ERR_ARG, "attn_bwd: null pointer");
   return attn_bwd(q_scaled, k, v, o, d_o, lse, delta_scratch, dq, dk, dv, S, heads, L, head_dim, qkv_row_stride, o_row_stride,
-                  do_row_stride, dqkv_row_stride, scale, (hipStream_t)stream);
+                  do_row_stride, dqkv_row_stride, scale, (hipStream_t)stream, key_limit);
 }
 
 int nova_row_norm(const void* in, void* out, const float* gamma, const float* beta, const void* mod, long mod_ld,
@@ -549,9 +550,10 @@ static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, con
 // per captured graph.
 // Calls that read per-call tensors the engine allocates afresh (ancestral noise, guidance-renorm scratch) and profiled
 // runs (HIP-event brackets around launches) stay on the direct path.
+static std::atomic<long> g_graph_epoch{0};  // bumped by nova_debug_set_graphs(0): every thread drops its cache at its next call
 struct DecoderGraphs {
   std::unordered_map<std::string, hipGraphExec_t> execs;
-  long captures = 0, replays = 0;
+  long captures = 0, replays = 0, epoch = 0;
   ~DecoderGraphs() { clear(); }
   void clear() {
     for (auto& kv : execs) (void)hipGraphExecDestroy(kv.second);
@@ -584,7 +586,15 @@ int nova_debug_set_attn_variant(int variant) {
 
 int nova_debug_set_graphs(int on) {
   g_graphs_on.store(on ? 1 : 0);
-  if (!on) g_dec_graphs.clear();
+  if (!on) {  // the calling thread's graphs go now, every other thread's at its next nova_decoder_denoise (the caches are thread-local)
+    g_graph_epoch.fetch_add(1);
+    g_dec_graphs.clear();
+  }
+  return 0;
+}
+
+int nova_debug_drop_graphs(void) {
+  g_dec_graphs.clear();
   return 0;
 }
 
@@ -611,6 +621,10 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
   if (direct)
     return decoder_denoise_launches(dec, zc, temb, x, sched, noise, renorm, echo_energy, steps, S, B, n, P, D, ws_a, ws_u, ws_h, ws_f,
                                     ws_g, ws_mod, ws_v, mod_steps, dtype, st);
+  if (const long e = g_graph_epoch.load(std::memory_order_relaxed); e != g_dec_graphs.epoch) {
+    g_dec_graphs.clear();
+    g_dec_graphs.epoch = e;
+  }
   std::string key;
   key.reserve(512 + sizeof(nova_sampler_step) * steps + sizeof(nova_mlp_block) * dec->depth);
   key_put(key, *dec);

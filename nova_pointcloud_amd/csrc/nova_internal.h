@@ -53,10 +53,11 @@ bool walk_is_reverse();
 // a KV cache of capacity cap rows per sequence passes cap * kv_row_stride.
 int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd,
              long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, hipStream_t st,
-             bool q_prescaled = false, long kv_seq_stride = 0, float* lse = nullptr);
+             bool q_prescaled = false, long kv_seq_stride = 0, float* lse = nullptr, const int* klim = nullptr);
 // attn16.hip: the same attention on the 16x16x32 MFMA shape (bf16, head_dim 64), 32 or 64 query rows per wave
 int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd, long q_rs, long kv_rs,
-                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined = false);
+                 long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined = false,
+                 const int* klim = nullptr);  // klim [Lq]: optional per-query key limit (training forward, block-causal frame mask)
 // 16x16x32, 32 rows per wave, row sums on the matrix pipe: +8 .. 11 % over variant 0 at every L measured (profiles/r03_attn_variants_ab.txt);
 // attn_fwd takes variant 4 (64 rows per wave) where its 256-row workgroups tile Lq exactly
 constexpr int NOVA_ATTN_DEFAULT_VARIANT = 3;
@@ -67,7 +68,7 @@ int attn_variant();
 // All matrices token-major [S, L, heads * hd] with row strides.
 int attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* d_o, const float* lse, float* delta, void* dq,
              void* dk, void* dv, int S, int heads, int L, int hd, long qkv_rs, long o_rs, long do_rs, long dqkv_rs, float scale,
-             hipStream_t st);
+             hipStream_t st, const int* klim = nullptr);  // klim [L]: optional per-query key limit (block-causal frame mask)
 
 // ---- rowops.hip
 struct RowNormArgs {

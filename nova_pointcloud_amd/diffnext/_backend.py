@@ -37,7 +37,8 @@ def autograd():
 
 
 def train_attention_supported(q, attn_mask):
-    """bf16 device tensors [S, heads, L, 64 | 96] without a mask: the case the HIP attention backward is built for."""
+    """bf16 device tensors [S, heads, L, 64 | 96] without a mask or with the block-causal frame mask: what the HIP attention
+    forward + backward are built for."""
     return q.is_cuda and autograd().attention_supported(q, attn_mask)
 
 

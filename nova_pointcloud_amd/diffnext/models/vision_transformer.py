@@ -89,7 +89,7 @@ class Attention(nn.Module):
         if self.cache_kv:
             k, v = self._extend_cache(k, v)
         if torch.is_grad_enabled() and not self.cache_kv and _backend.train_attention_supported(q, self.attn_mask):
-            out = _backend.autograd().attention(q, k, v)  # training on the GPU: HIP flash forward + backward (csrc/attn_bwd.hip)
+            out = _backend.autograd().attention(q, k, v, self.attn_mask)  # training on the GPU: HIP flash forward + backward (csrc/attn_bwd.hip)
         else:
             out = F.scaled_dot_product_attention(q, k, v, attn_mask=self.attn_mask)
         return self.proj(out.transpose(1, 2).flatten(2))

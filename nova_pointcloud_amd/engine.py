@@ -248,6 +248,8 @@ class NovaEngine(object):
         """Scratch buffers of one lane, reallocated only when the shapes (or dtype / fp8 mode) change."""
         key = (S, B, N, L, nmax, self.dtype, self.dev, self.fp8, steps)
         if self.ws.get(lane, (None, None))[0] != key:
+            if lane in self.ws:  # the graphs captured for the old buffers' addresses can never be replayed again: drop them
+                hip.call("nova_debug_drop_graphs")
             D, dt, dev = self.D, self.dtype, self.dev
             e = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
             rows = S * L

@@ -89,8 +89,8 @@ SIGNATURES = {
     "nova_pointset_nn_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_int, c_void_p],
     "nova_pointset_pairwise_dist": [c_void_p] * 3 + [c_int] * 3 + [c_float, c_float, c_void_p],
     "nova_modulate_rows": [c_void_p] * 3 + [c_long, c_int, c_int, c_void_p],
-    "nova_attn_fwd_lse": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_long, c_long, c_void_p],
-    "nova_attn_bwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_void_p],
+    "nova_attn_fwd_lse": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_long, c_long, c_void_p, c_void_p],
+    "nova_attn_bwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_void_p, c_void_p],
     "nova_row_norm_bwd": [c_void_p] * 5 + [c_long, c_int, c_int, c_int] + [c_void_p] * 4 + [c_int, c_long, c_int, c_float, c_int, c_void_p],
     "nova_row_norm_chain": [c_void_p] * 5 + [c_long, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "nova_adaln_fc1": [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_long]
@@ -102,6 +102,7 @@ SIGNATURES["nova_prof_enable"] = [c_int]
 SIGNATURES["nova_debug_force_gemm_tile"] = [c_int]
 SIGNATURES["nova_debug_set_graphs"] = [c_int]
 SIGNATURES["nova_debug_set_attn_variant"] = [c_int]
+SIGNATURES["nova_debug_drop_graphs"] = []
 SIGNATURES["nova_debug_graph_stats"] = [ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
 SIGNATURES["nova_prof_collect"] = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_longlong), c_int]

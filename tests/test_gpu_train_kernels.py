@@ -276,3 +276,59 @@ def test_training_modules_take_the_fused_norm_and_match_the_torch_definition(hip
             assert _rel(gi, t.grad) < 1e-3
         for n, p in mod.named_parameters():
             assert _rel(grads[n], p.grad) < 1e-3, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Block-causal frame mask of multi-frame training (reference embeddings.py:247-260, transformer_3d.py:176-177) as a per-query key limit
+# ---------------------------------------------------------------------------------------------------------------------
+def _frame_mask(prefix, frames, per_frame, device="cuda", dtype=torch.bfloat16):
+    """What MaskEmbed.get_attn_mask builds: token i sees token j iff frame(i) >= frame(j), the prefix counting as frame 0."""
+    d = torch.cat([torch.zeros(prefix), torch.arange(frames).repeat_interleave(per_frame)])
+    return torch.where(d[:, None] >= d[None, :], 0.0, float("-inf")).to(device=device, dtype=dtype)
+
+
+@pytest.mark.parametrize("hd", [64, 96])
+@pytest.mark.parametrize("S,h,prefix,frames,per_frame", [(2, 2, 8, 3, 40), (1, 3, 37, 4, 100), (2, 1, 0, 5, 64), (1, 2, 300, 2, 333)])
+def test_masked_attention_forward_backward_match_autograd(hip, S, h, prefix, frames, per_frame, hd):
+    from nova_pointcloud_amd import autograd as A
+
+    L = prefix + frames * per_frame
+    g = torch.Generator().manual_seed(L + hd)
+    mk = lambda s: (torch.randn(S, h, L, hd, generator=g) * s).bfloat16().cuda()
+    q, k, v, d_out = mk(2.0), mk(1.0), mk(1.0), mk(1.0)
+    q, k, v = (t.requires_grad_(True) for t in (q, k, v))
+    mask = _frame_mask(prefix, frames, per_frame)
+    limit = A.key_limit_of_mask(mask)
+    assert limit is not None and limit.dtype == torch.int32 and int(limit[0]) == prefix + per_frame and int(limit[-1]) == L
+    assert A.key_limit_of_mask(mask) is limit  # cached per mask tensor
+    assert A.attention_supported(q, mask)
+    out = A.attention(q, k, v, mask)
+    out.backward(d_out)
+    qf, kf, vf = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qf, kf, vf, attn_mask=mask.float())
+    ref.backward(d_out.float())
+    assert _rel(out, ref.detach()) < 1.6e-2
+    for name, got, want in (("dq", q.grad, qf.grad), ("dk", k.grad, kf.grad), ("dv", v.grad, vf.grad)):
+        assert torch.isfinite(got.float()).all(), name
+        assert _rel(got, want) < 2e-2, (name, _rel(got, want))
+    # rows of the first frame must not depend on later frames at all: perturbing the last frame's keys / values leaves them bit-identical
+    with torch.no_grad():
+        k2, v2 = k.detach().clone(), v.detach().clone()
+        k2[:, :, -per_frame:] += 1.0
+        v2[:, :, -per_frame:] -= 1.0
+        again = A.attention(q.detach(), k2, v2, mask)
+    first = prefix + per_frame
+    assert torch.equal(again[:, :, :first], out.detach()[:, :, :first])
+
+
+def test_masks_that_are_not_key_limits_are_refused(hip):
+    from nova_pointcloud_amd import autograd as A
+
+    L = 64
+    q = torch.zeros(1, 1, L, 64, dtype=torch.bfloat16, device="cuda")
+    band = torch.full((L, L), float("-inf"), device="cuda").triu(5).tril(-1) * 0  # zeros: everything visible -> a valid (trivial) limit
+    assert A.attention_supported(q, band.bfloat16())
+    anti = torch.where(torch.arange(L)[:, None] <= torch.arange(L)[None, :], 0.0, float("-inf")).cuda()  # sees only LATER keys: no prefix form
+    assert A.key_limit_of_mask(anti) is None and not A.attention_supported(q, anti)
+    bias = torch.randn(L, L, device="cuda")  # finite biases are not a visibility mask
+    assert not A.attention_supported(q, bias)
