@@ -130,7 +130,7 @@ def cpu_baseline(pipe, width, heads, H, W, threads, with_config0=False):
 
 PMC_KERNEL_FP8 = {"attention": "attn_bf16_m16<bf16,96,2,false,true,false>", "gemm_bias": "gemm256p_kernel<fp8,0>", "gemm_bias_gelu": "gemm256p_kernel<fp8,5>",
                   "qkv_gemm_rope": "gemm256p_kernel<fp8,3>"}
-PMC_KERNEL = {"attention": "attn_bf16_m16<bf16,64,4,false,true,false>",  # the L = 2560 launch of the counter passes (64 rows per wave there) "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
+PMC_KERNEL = {"attention": "attn_bf16_m16<bf16,64,2,false,true,false>", "gemm_bias": "gemm256p_kernel<bf16,0>", "gemm_bias_gelu": "gemm256p_kernel<bf16,1>",
               "qkv_gemm_rope": "gemm256p_kernel<bf16,3>"}
 
 

@@ -416,11 +416,11 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
     const int rev = walk_is_reverse() ? 1 : 0;
     if (klim) return attn_fwd_m16(q, k, v, o, S, heads, Lq, Lk, hd, q_rs, kv_rs, o_rs, cl, dtype, st, kv_ss, lse, 32, true, false, klim);
     if (attn_variant() != 0) {
-      // the shipped choice: 16x16x32 with the row sums on the matrix pipe; 64 query rows per wave where the 256-row workgroups
-      // tile the queries exactly and there are many of them (the full-length encoder blocks: +1.3 .. 2 % over 32 rows per wave
-      // at L = 2560, -5 .. 10 % at ragged or short L: profiles/r03_attn_variants_ab.txt). Depends on Lq only, never on the batch.
-      int av = attn_variant();
-      if (g_attn_variant < 0 && av == 3 && hd == 64 && Lq >= 2048 && Lq % 256 == 0) av = 4;
+      // the shipped choice: 16x16x32, 32 query rows per wave, row sums on the matrix pipe, at every length. (64 rows per wave where
+      // 256-row workgroups tile the queries exactly is +1.3 .. 2 % standalone at L = 2560 - profiles/r03_attn_variants_ab.txt - but
+      // measured ~5 % SLOWER inside the generation step, where two lanes share the chip: attention / plain-GEMM rate 0.78 against 0.82
+      // over four bench runs; it also re-fetches 7 % more K / V, L2 hit 83 % against 91 %.)
+      const int av = attn_variant();
       return attn_fwd_m16(q, k, v, o, S, heads, Lq, Lk, hd, q_rs, kv_rs, o_rs, cl, dtype, st, kv_ss, lse, (av & 1) && av != 5 ? 32 : 64, av >= 3,
                           av == 5);
     }

@@ -58,8 +58,7 @@ int attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int he
 int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd, long q_rs, long kv_rs,
                  long o_rs, float cl, int dtype, hipStream_t st, long kv_ss, float* lse, int rows_per_wave, bool sum_on_mfma, bool pipelined = false,
                  const int* klim = nullptr);  // klim [Lq]: optional per-query key limit (training forward, block-causal frame mask)
-// 16x16x32, 32 rows per wave, row sums on the matrix pipe: +8 .. 11 % over variant 0 at every L measured (profiles/r03_attn_variants_ab.txt);
-// attn_fwd takes variant 4 (64 rows per wave) where its 256-row workgroups tile Lq exactly
+// 16x16x32, 32 rows per wave, row sums on the matrix pipe: +8 .. 11 % over variant 0 at every L measured (profiles/r03_attn_variants_ab.txt)
 constexpr int NOVA_ATTN_DEFAULT_VARIANT = 3;
 int attn_set_variant(int v);  // -1 default, 0 .. 5 (attn.hip); -1 returned for other values
 int attn_variant();
