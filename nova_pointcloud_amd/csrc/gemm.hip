@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
                    hipStream_t st, bool one_tile_per_workgroup = false);
+int gemm256_cu_count();  // CUs of the device = the persistent kernel's grid
 
 // 0 = auto, 128 / 256 = force that tile structure (tests compare the two structures bit for bit). Thread-local like
 // the walk direction: a debugging knob of the calling host thread, not shared state.
@@ -245,7 +246,12 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
     return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
   const bool can256 = N % 256 == 0 && (epi != EPI_ROPE || (e.rope_cols % 256 == 0 && e.q_cols % 256 == 0));  // rotation is decided per tile
   if (g_force_tile >= 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
-  if (can256 && (g_force_tile >= 256 || (g_force_tile == 0 && M >= 4096)))
+  // The persistent 256 kernel needs tiles to spread over the chip: with fewer 256 x 256 tiles than half the CUs (batch 1: 20 row
+  // panels x 4 column tiles for the out-projection and fc2) the 128 tile takes the launch. End to end at batch 1: 702 against
+  // 722 ms per sample; a threshold of one tile per CU, which also moves the 160-tile launches of batch 2, loses 2.4 % there
+  // (profiles/r03_gemm_min_tiles_ab.txt). Shapes of batch >= 4 have 320 tiles or more and are not touched.
+  const long tiles256 = (long)((M + 255) / 256) * (N / 256);
+  if (can256 && (g_force_tile >= 256 || (g_force_tile == 0 && M >= 4096 && 2 * tiles256 >= gemm256_cu_count())))
     return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols, e.q_scale, e.q_cols,
                           dtype_of<T>(), st, g_force_tile == 257);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;

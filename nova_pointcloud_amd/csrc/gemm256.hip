@@ -709,6 +709,8 @@ static int cu_slots() {  // persistent grid: one workgroup per CU, a multiple of
   return n;
 }
 
+int gemm256_cu_count() { return cu_slots(); }  // the persistent grid = CUs of the device (gemm.hip's kernel choice reads it)
+
 template <typename T>
 static int launch256p(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
                       hipStream_t st) {
