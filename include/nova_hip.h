@@ -145,6 +145,17 @@ int nova_attn_bwd(const void* q_scaled, const void* k, const void* v, const void
                   long qkv_row_stride, long o_row_stride, long do_row_stride, long dqkv_row_stride, float scale,
                   const int* key_limit, void* stream);
 
+/* ---- training side, pointwise -------------------------------------------
+ * The activation between the two projections of an MLP, forward and backward, n contiguous elements of `dtype`
+ * (n a multiple of 16 bytes' worth: 4 floats / 8 16-bit values), arithmetic in f32:
+ *   kind NOVA_ACT_GELU_ERF: y = 0.5 x (1 + erf(x / sqrt 2)), the exact form of nn.GELU() the reference trains with
+ *                           (vision_transformer.py:33-38); dx = dy (Phi(x) + x phi(x))
+ *   kind NOVA_ACT_SILU:     y = x / (1 + e^-x) (the decoder MLP, diffusion_mlp.py:33,36; SiLU(z) of AdaLayerNormZero,
+ *                           normalization.py:32,35); dx = dy s (1 + x (1 - s)), s = 1 / (1 + e^-x)
+ * The forward keeps nothing but x; the backward recomputes the slope from it. */
+int nova_act_fwd(const void* x, void* y, long long n, int kind, int dtype, void* stream);
+int nova_act_bwd(const void* x, const void* dy, void* dx, long long n, int kind, int dtype, void* stream);
+
 /* ---- training: backward of the LayerNorm family --------------------------------------------------------------------
  * For y = LN(x; eps) [* gamma + beta] [* (1 + scale) + shift] [* gate] [+ res] (nova_row_norm's forward) and the output
  * gradient dy [rows, D]: dx [rows, D]; d_scale / d_shift / d_gate written into dmod [rows, mod_ld] at the forward's offsets

@@ -210,3 +210,44 @@ class NovaFusedNormFunction(torch.autograd.Function):
 def fused_norm(x, gamma=None, beta=None, scale=None, shift=None, gate=None, res=None, eps=1e-5):
     """y = LN(x; eps) [* gamma + beta] [* (1 + scale) + shift] [* gate] [+ res], differentiable; one HIP row kernel each way."""
     return NovaFusedNormFunction.apply(x, gamma, beta, scale, shift, gate, res, eps)
+
+
+# ---- pointwise activations of the MLPs (csrc/rownorm_bwd.hip: act_kernel) ----------------------------------------------------
+_ACT_ENABLED = os.environ.get("NOVA_TRAIN_ACT", "1") != "0"  # read once
+ACT_GELU, ACT_SILU = 1, 2  # nova_act of include/nova_hip.h
+stats["act_calls"] = 0
+
+
+def activation_supported(x):
+    """GPU tensor of a storage type the library knows, whole 16-byte chunks (every width of the model is a multiple of 8)."""
+    if not (_ACT_ENABLED and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16, torch.float16)):
+        return False
+    return x.numel() > 0 and x.numel() % (4 if x.dtype == torch.float32 else 8) == 0
+
+
+class NovaActivationFunction(torch.autograd.Function):
+    """y = gelu(x) (exact erf form, nn.GELU()) or silu(x); the backward recomputes the slope from x (nothing else is saved)."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        hip.load()
+        stats["act_calls"] += 1
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        hip.call("nova_act_fwd", xc.data_ptr(), y.data_ptr(), xc.numel(), int(kind), hip.dtype_code(xc.dtype), hip.stream_ptr())
+        ctx.save_for_backward(xc)
+        ctx.kind = int(kind)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        dyc = dy.to(xc.dtype).contiguous()
+        dx = torch.empty_like(xc)
+        hip.call("nova_act_bwd", xc.data_ptr(), dyc.data_ptr(), dx.data_ptr(), xc.numel(), ctx.kind, hip.dtype_code(xc.dtype), hip.stream_ptr())
+        return dx, None
+
+
+def activation(x, kind):
+    """gelu / silu of `x`, differentiable; one HIP pointwise kernel each way (ACT_GELU / ACT_SILU)."""
+    return NovaActivationFunction.apply(x, kind)

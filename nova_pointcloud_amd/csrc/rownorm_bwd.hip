@@ -184,7 +184,77 @@ int row_norm_bwd(const RowNormBwdArgs& a, int parts, int dtype, hipStream_t st) 
   return check_launch("row_norm_bwd");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Training side, pointwise: the activations between the two projections of an MLP, forward and backward in f32 registers on the
+// storage type's values. GELU is the exact erf form the reference trains with (nn.GELU(), vision_transformer.py:33-38; the fitted
+// form of common.h is the generation path's), SiLU the DiffusionBlock's (diffusion_mlp.py:31-36):
+//   gelu(x) = x Phi(x),  gelu'(x) = Phi(x) + x phi(x);     silu(x) = x s(x),  silu'(x) = s (1 + x (1 - s)),  s = 1 / (1 + e^-x)
+// HBM-bound: forward reads x and writes y, backward reads x and dy and writes dx (nothing but x is kept by the forward).
+template <int KIND> __device__ __forceinline__ float act_value(float x) { return KIND == NOVA_ACT_GELU_ERF ? gelu_erf(x) : silu(x); }
+template <int KIND> __device__ __forceinline__ float act_slope(float x) {
+  if (KIND == NOVA_ACT_GELU_ERF) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    return cdf + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+  }
+  const float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+template <typename T, int KIND, bool BWD>
+__global__ __launch_bounds__(256) void act_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ out, long n) {
+  using C = Chunk<T>;  // 16 bytes per lane: 8 values of a 16-bit type, 4 floats
+  const long nchunks = n / C::N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+    C v = C::load(x + i * C::N), g, o;
+    if (BWD) g = C::load(dy + i * C::N);
+#pragma unroll
+    for (int k = 0; k < C::N / 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.v[k][j] = BWD ? g.v[k][j] * act_slope<KIND>(v.v[k][j]) : act_value<KIND>(v.v[k][j]);
+    o.store(out + i * C::N);
+  }
+}
+
+// forward: dy == nullptr, out = act(x); backward: out = dy * act'(x). n % (16 / element size) == 0 (whole 16-byte chunks).
+int act_pointwise(const void* x, const void* dy, void* out, long n, int kind, int dtype, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (kind != NOVA_ACT_GELU_ERF && kind != NOVA_ACT_SILU) return set_error(NOVA_ERR_ARG, "act: kind must be NOVA_ACT_GELU_ERF or NOVA_ACT_SILU (got %d)", kind);
+  const int vec = dtype_is16(dtype) ? 8 : 4;
+  if (n % vec) return set_error(NOVA_ERR_SHAPE, "act: element count %ld is not a multiple of %d", n, vec);
+  const long nchunks = n / vec;
+  const int blocks = (int)((nchunks + 255) / 256 > 16384 ? 16384 : (nchunks + 255) / 256);
+  dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    const T* xp = static_cast<const T*>(x);
+    const T* gp = static_cast<const T*>(dy);
+    T* op = static_cast<T*>(out);
+    if (kind == NOVA_ACT_GELU_ERF) {
+      if (dy) hipLaunchKernelGGL((act_kernel<T, NOVA_ACT_GELU_ERF, true>), dim3(blocks), dim3(256), 0, st, xp, gp, op, n);
+      else hipLaunchKernelGGL((act_kernel<T, NOVA_ACT_GELU_ERF, false>), dim3(blocks), dim3(256), 0, st, xp, gp, op, n);
+    } else {
+      if (dy) hipLaunchKernelGGL((act_kernel<T, NOVA_ACT_SILU, true>), dim3(blocks), dim3(256), 0, st, xp, gp, op, n);
+      else hipLaunchKernelGGL((act_kernel<T, NOVA_ACT_SILU, false>), dim3(blocks), dim3(256), 0, st, xp, gp, op, n);
+    }
+    return 0;
+  });
+  return check_launch("act");
+}
+
 }  // namespace nova
+
+extern "C" int nova_act_fwd(const void* x, void* y, long long n, int kind, int dtype, void* stream) {
+  using namespace nova;
+  if (dtype != NOVA_F32 && dtype != NOVA_BF16 && dtype != NOVA_F16) return set_error(NOVA_ERR_ARG, "act_fwd: bad dtype %d", dtype);
+  if (n > 0 && (!x || !y)) return set_error(NOVA_ERR_ARG, "act_fwd: null pointer");
+  return act_pointwise(x, nullptr, y, (long)n, kind, dtype, (hipStream_t)stream);
+}
+
+extern "C" int nova_act_bwd(const void* x, const void* dy, void* dx, long long n, int kind, int dtype, void* stream) {
+  using namespace nova;
+  if (dtype != NOVA_F32 && dtype != NOVA_BF16 && dtype != NOVA_F16) return set_error(NOVA_ERR_ARG, "act_bwd: bad dtype %d", dtype);
+  if (n > 0 && (!x || !dy || !dx)) return set_error(NOVA_ERR_ARG, "act_bwd: null pointer");
+  return act_pointwise(x, dy, dx, (long)n, kind, dtype, (hipStream_t)stream);
+}
 
 extern "C" int nova_row_norm_bwd(const void* x, const void* dy, const float* gamma, const float* beta, const void* mod, long mod_ld,
                                  int scale_off, int shift_off, int gate_off, void* dx, void* dmod, float* dgamma_part,

@@ -47,3 +47,13 @@ def train_norm_supported(x, **terms):
     import torch
 
     return x.is_cuda and torch.is_grad_enabled() and autograd().fused_norm_supported(x, **terms)
+
+
+def train_activation(x, kind, fallback):
+    """Training on the GPU (autograd on): gelu (kind 1, the exact erf form) / silu (kind 2) as one HIP pointwise kernel each way
+    (autograd.activation, csrc/rownorm_bwd.hip); everywhere else `fallback(x)`, the torch op of the reference module."""
+    import torch
+
+    if x.is_cuda and torch.is_grad_enabled() and autograd().activation_supported(x):
+        return autograd().activation(x, kind)
+    return fallback(x)

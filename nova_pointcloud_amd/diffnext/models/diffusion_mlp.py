@@ -33,7 +33,7 @@ class Projector(nn.Module):
         self.activation = nn.SiLU()
 
     def forward(self, x) -> torch.Tensor:
-        return self.fc2(F.silu(self.fc1(x)))
+        return self.fc2(_backend.train_activation(self.fc1(x), 2, F.silu))
 
 
 class TimeCondEmbed(nn.Module):

@@ -34,7 +34,7 @@ class AdaLayerNormZero(nn.Module):
         self.norm = nn.LayerNorm(dim, eps, elementwise_affine=False) if eps else nn.Identity()
 
     def statistics(self, z):
-        return self.proj(self.lora(F.silu(z))).chunk(self.num_stats, dim=-1)
+        return self.proj(self.lora(_backend.train_activation(z, 2, F.silu))).chunk(self.num_stats, dim=-1)
 
     def forward(self, x, z) -> Tuple[torch.Tensor, Tuple[torch.Tensor]]:
         scale, shift, *rest = self.statistics(z)

@@ -107,7 +107,7 @@ class MLP(nn.Module):
 
     def forward(self, x) -> torch.Tensor:
         if not use_hip(x):
-            return self.fc2(self.activation(self.fc1(x)))
+            return self.fc2(_backend.train_activation(self.fc1(x), 1, self.activation))
         hip = _backend.hip()
         rows = x.reshape(-1, x.size(-1)).contiguous()
         hidden = hip.gemm_bias_act(rows, _w(self.fc1, x), _b(self.fc1), hip.ACT_GELU_ERF)

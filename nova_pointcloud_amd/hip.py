@@ -92,6 +92,8 @@ SIGNATURES = {
     "nova_attn_fwd_lse": [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_long, c_long, c_void_p, c_void_p],
     "nova_attn_bwd": [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_float, c_void_p, c_void_p],
     "nova_row_norm_bwd": [c_void_p] * 5 + [c_long, c_int, c_int, c_int] + [c_void_p] * 4 + [c_int, c_long, c_int, c_float, c_int, c_void_p],
+    "nova_act_fwd": [c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p],
+    "nova_act_bwd": [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p],
     "nova_row_norm_chain": [c_void_p] * 5 + [c_long, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_long, c_int, c_int, c_void_p],
     "nova_adaln_fc1": [c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_long]
     + [c_int] * 4 + [c_void_p],

@@ -279,6 +279,93 @@ def test_training_modules_take_the_fused_norm_and_match_the_torch_definition(hip
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Pointwise activations of the MLPs, forward and backward (csrc/rownorm_bwd.hip act_kernel; reference vision_transformer.py:35,38
+# nn.GELU(), diffusion_mlp.py:33,36 and normalization.py:32,35 nn.SiLU())
+# ---------------------------------------------------------------------------------------------------------------------
+# elementwise bound |got - ref| <= rtol |ref| + atol against PyTorch's f32 result on the same (storage-rounded) inputs:
+# f32: a few ulp of erff / expf; 16-bit: half an ulp of the storage type (2^-9 bf16, 2^-12 f16) on the rounded result, doubled
+ACT_TOL = {torch.float32: (2e-6, 2e-6), torch.bfloat16: (2 ** -8, 1e-6), torch.float16: (2 ** -11, 1e-6)}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("kind", ["gelu", "silu"])
+@pytest.mark.parametrize("shape", [(8,), (3, 37, 128), (2, 300, 3072), (5000, 1024)])
+def test_activation_forward_backward_match_autograd(hip, dtype, kind, shape):
+    from nova_pointcloud_amd import autograd as A
+
+    g = torch.Generator().manual_seed(100 * len(shape) + shape[-1] % 97 + (0 if kind == "gelu" else 7))
+    x = torch.randn(*shape, generator=g) * 2.5
+    flat = x.view(-1)
+    flat[:8] = torch.tensor([0.0, -0.0, 8.0, -8.0, 30.0, -30.0, -0.7518, 1e-4])[: flat.numel()]  # zeros, both tails, gelu' = 0, tiny
+    dy = torch.randn(*shape, generator=g)
+    x, dy = x.to(dtype).cuda(), dy.to(dtype).cuda()
+    fn = (lambda t: torch.nn.functional.gelu(t)) if kind == "gelu" else torch.nn.functional.silu
+    xr = x.detach().float().clone().requires_grad_(True)  # (.float() of an f32 tensor is the tensor itself: clone before requires_grad_)
+    ref = fn(xr)
+    ref.backward(dy.float())
+    assert A.activation_supported(x)
+    xa = x.detach().clone().requires_grad_(True)
+    y = A.activation(xa, A.ACT_GELU if kind == "gelu" else A.ACT_SILU)
+    y.backward(dy)
+    assert y.dtype == dtype and xa.grad.dtype == dtype and y.shape == x.shape
+    rtol, atol = ACT_TOL[dtype]
+    torch.testing.assert_close(y.float(), ref.detach(), rtol=rtol, atol=atol)
+    torch.testing.assert_close(xa.grad.float(), xr.grad, rtol=rtol, atol=atol * max(1.0, dy.float().abs().max().item()))
+
+
+def test_activation_refuses_ragged_sizes_and_unknown_kinds(hip):
+    """Whole 16-byte chunks only: the predicate says no (the modules then take the torch op), the C entry point says why."""
+    from nova_pointcloud_amd import autograd as A
+
+    x = torch.randn(13, device="cuda", dtype=torch.bfloat16)
+    assert not A.activation_supported(x)
+    assert not A.activation_supported(torch.randn(16))  # host tensor
+    y = torch.empty_like(x)
+    with pytest.raises(hip.NovaHipError, match="multiple"):
+        hip.call("nova_act_fwd", x.data_ptr(), y.data_ptr(), x.numel(), 1, hip.dtype_code(x.dtype), hip.stream_ptr())
+    x16 = torch.randn(16, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(hip.NovaHipError, match="kind"):
+        hip.call("nova_act_fwd", x16.data_ptr(), torch.empty_like(x16).data_ptr(), 16, 7, hip.dtype_code(x16.dtype), hip.stream_ptr())
+
+
+def test_training_modules_take_the_hip_activation_and_match_the_torch_definition(hip):
+    """MLP (GELU), the decoder's MLP and AdaLayerNormZero (SiLU) with autograd on, on the GPU: the HIP activation is what runs
+    (call counter), outputs and every gradient match the same modules with it switched off; under no_grad it is not taken."""
+    from diffnext.models.diffusion_mlp import DiffusionBlock
+    from diffnext.models.vision_transformer import Block
+    from nova_pointcloud_amd import autograd as A
+
+    torch.manual_seed(11)
+    for make, args in ((lambda: Block(256, 4), lambda: (torch.randn(2, 70, 256) * 0.7,)),
+                       (lambda: DiffusionBlock(256), lambda: (torch.randn(2, 70, 256) * 0.7, torch.randn(2, 70, 256) * 0.7))):
+        mod = make().cuda().float()
+        with torch.no_grad():
+            for p in mod.parameters():
+                p.add_(torch.randn_like(p) * 0.02)
+        ins = [t.cuda().requires_grad_(True) for t in args()]
+        before = A.stats["act_calls"]
+        out = mod(*ins)
+        out.square().mean().backward()
+        assert A.stats["act_calls"] > before, type(mod).__name__
+        grads = {n: p.grad.clone() for n, p in mod.named_parameters()}
+        gin = [t.grad.clone() for t in ins]
+        mod.zero_grad()
+        for t in ins:
+            t.grad = None
+        A._ACT_ENABLED = False
+        try:
+            ref = mod(*ins)
+            ref.square().mean().backward()
+        finally:
+            A._ACT_ENABLED = True
+        assert _rel(out.detach(), ref.detach()) < 1e-5
+        for t, gi in zip(ins, gin):
+            assert _rel(gi, t.grad) < 1e-4
+        for n, p in mod.named_parameters():
+            assert _rel(grads[n], p.grad) < 1e-4, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Block-causal frame mask of multi-frame training (reference embeddings.py:247-260, transformer_3d.py:176-177) as a per-query key limit
 # ---------------------------------------------------------------------------------------------------------------------
 def _frame_mask(prefix, frames, per_frame, device="cuda", dtype=torch.bfloat16):

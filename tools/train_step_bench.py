@@ -1,6 +1,6 @@
 """One training step (forward + backward of Transformer3DModel.train_video) of a random-init BASELINE architecture in bf16
 on one MI355X, with the HIP training kernels (attention: csrc/attn16.hip + attn_bwd.hip; LayerNorm family: rowops.hip +
-rownorm_bwd.hip) switched on and off, same process.
+rownorm_bwd.hip; GELU / SiLU: rownorm_bwd.hip act_kernel) switched on and off, same process.
 
     python3 tools/train_step_bench.py [workload] [batch]        # default d48w1024_2048pts_b32, batch 8
 """
@@ -35,8 +35,8 @@ def step():
     return float(out["loss"].detach())
 
 
-for use_hip, use_norm in ((True, True), (True, False), (False, False), (True, True), (True, False), (False, False)):
-    A._ENABLED, A._NORM_ENABLED = use_hip, use_norm
+for use_hip, use_norm, use_act in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)) * 2:
+    A._ENABLED, A._NORM_ENABLED, A._ACT_ENABLED = use_hip, use_norm, use_act
     step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -44,5 +44,5 @@ for use_hip, use_norm in ((True, True), (True, False), (False, False), (True, Tr
         loss = step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
-    print(f"{workload} batch {B} attention={'HIP' if use_hip else 'torch SDPA'} norms={'HIP fused' if use_norm else 'torch'}: {ms:.0f} ms per forward+backward, loss {loss:.4f}, "
+    print(f"{workload} batch {B} attention={'HIP' if use_hip else 'torch SDPA'} norms={'HIP fused' if use_norm else 'torch'} activations={'HIP' if use_act else 'torch'}: {ms:.0f} ms per forward+backward, loss {loss:.4f}, "
           f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
