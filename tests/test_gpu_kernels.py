@@ -323,6 +323,22 @@ def test_gemm_256_tile_bitwise_equals_128_tile(hip, force_tile, form, dtype, M, 
     assert relerr(out, full) < tol(dtype)
 
 
+@pytest.mark.parametrize("M,N,K", [(5120, 1024, 1024), (5120, 1024, 4096), (5120, 3072, 1024), (10240, 1024, 1024), (40960, 1024, 1024)])
+def test_gemm_automatic_kernel_choice_never_shows_in_the_output(hip, force_tile, M, N, K):
+    """The library picks the tile structure by shape (gemm.hip: the persistent 256 kernel from M >= 4096 rows on, unless its tiles
+    would cover less than half the CUs - batch 1's out-projection and fc2, 80 tiles - where the 128 tile takes the launch).
+    Whatever it picks is bit-identical to both forced structures, so batch size and the rule's threshold never change a result."""
+    a, w = rnd(M, K, dtype=torch.bfloat16, seed=51), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=52)
+    bias = rnd(N, seed=53)
+    auto = hip.gemm_bias_act(a, w, bias, 0)
+    force_tile(128)
+    t128 = hip.gemm_bias_act(a, w, bias, 0)
+    force_tile(256)
+    t256 = hip.gemm_bias_act(a, w, bias, 0)
+    assert torch.equal(auto, t128) and torch.equal(auto, t256)
+    assert relerr(auto, a.float() @ w.float().T + bias) < tol(torch.bfloat16)
+
+
 @pytest.mark.parametrize("M,N,K,act", [(1, 768, 768, 0), (16, 768, 768, 2), (200, 768, 768, 2), (257, 3072, 768, 1), (999, 1024, 1024, 2),
                                         (130, 4096, 1024, 1), (64, 64, 1024, 0), (1500, 1024, 1024, 2), (3000, 768, 768, 0)])
 @pytest.mark.parametrize("dtype", HALF)
