@@ -554,8 +554,12 @@ static std::atomic<long> g_graph_epoch{0};  // bumped by nova_debug_set_graphs(0
 struct DecoderGraphs {
   std::unordered_map<std::string, hipGraphExec_t> execs;
   long captures = 0, replays = 0, epoch = 0;
-  ~DecoderGraphs() { clear(); }
-  void clear() {
+  ~DecoderGraphs() { clear(false); }  // thread exit / process teardown: the runtime may already be going down, no device call but the destroys
+  // A launch of one of these execs may still be queued or running on some stream (the host runs ahead of the device, and the caller
+  // drops the cache exactly when it is about to re-plan: a workspace that changed shape, graphs switched off): wait for the device
+  // before the execs and their kernel-argument storage go. Rare by construction (shape changes), so the wait is not a cost.
+  void clear(bool wait = true) {
+    if (wait && !execs.empty()) (void)hipDeviceSynchronize();
     for (auto& kv : execs) (void)hipGraphExecDestroy(kv.second);
     execs.clear();
   }

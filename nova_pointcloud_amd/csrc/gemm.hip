@@ -14,6 +14,7 @@
 // A operand so each lane ends up holding 4 consecutive output columns of one row: bias / GELU /
 // SiLU / RoPE pairs are lane-local and the store is 8 B (bf16) or 16 B (f32) per lane.
 // bf16: v_mfma_f32_16x16x32_bf16; f32 (parity mode): v_mfma_f32_16x16x4_f32 (exact f32).
+#include <cstdlib>
 #include "common.h"
 #include "nova_internal.h"
 
@@ -237,6 +238,16 @@ int gemm_force_tile(int tile) {
   return 0;             // 16: the small-M kernel of skinny.hip wherever its shapes allow (an error elsewhere)
 }
 
+// fewest 256 x 256 tiles the persistent kernel is given a launch for: half the CUs, or NOVA_GEMM_MIN_TILES (read once; 0 = no lower
+// bound, the rule of rounds 1-2)
+static long min_tiles256() {
+  static const long v = [] {
+    const char* e = getenv("NOVA_GEMM_MIN_TILES");
+    return e && *e ? atol(e) : (long)gemm256_cu_count() / 2;
+  }();
+  return v;
+}
+
 template <typename T>
 static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi& e,
                        hipStream_t st) {
@@ -251,7 +262,7 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
   // 722 ms per sample; a threshold of one tile per CU, which also moves the 160-tile launches of batch 2, loses 2.4 % there
   // (profiles/r03_gemm_min_tiles_ab.txt). Shapes of batch >= 4 have 320 tiles or more and are not touched.
   const long tiles256 = (long)((M + 255) / 256) * (N / 256);
-  if (can256 && (g_force_tile >= 256 || (g_force_tile == 0 && M >= 4096 && 2 * tiles256 >= gemm256_cu_count())))
+  if (can256 && (g_force_tile >= 256 || (g_force_tile == 0 && M >= 4096 && tiles256 >= min_tiles256())))
     return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols, e.q_scale, e.q_cols,
                           dtype_of<T>(), st, g_force_tile == 257);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;

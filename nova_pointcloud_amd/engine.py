@@ -27,6 +27,7 @@ import torch
 from . import hip
 
 _F32 = torch.float32
+_POISON_WS = os.environ.get("NOVA_POISON_WS", "0") == "1"  # fill freshly allocated lane workspaces with NaN / -1 (debugging aid)
 # default number of half-batch lanes; read ONCE at import (an experiment knob of tools/lanes_ab.py, 0 = the rule below)
 _ENV_LANES = int(os.environ.get("NOVA_LANES", "0") or 0)
 
@@ -266,6 +267,12 @@ class NovaEngine(object):
                       ids_cat=torch.empty(S * nmax, dtype=torch.int64, device=dev), rope1=torch.empty(B * L * (D // self.heads), dtype=_F32, device=dev),
                       rope_q=torch.empty(B * nmax * (D // self.heads), dtype=_F32, device=dev), lq=e(S * nmax, D), lx=e(S * nmax, D), lo=e(S * nmax, D),
                       lh=e(S * nmax, self.hidden), lz=e(S * nmax, D), lz2=e(S * nmax, D))
+            if _POISON_WS:  # debugging aid: a read of a never-written scratch element shows as NaN instead of depending on what the
+                for v in ws.values():  # allocator handed out (NOVA_POISON_WS=1, read once at import)
+                    if torch.is_tensor(v) and v.is_floating_point():
+                        v.fill_(float("nan"))
+                    elif torch.is_tensor(v):
+                        v.fill_(-1 if v.dtype == torch.int64 else 0xFF)
             self.ws[lane] = (key, ws)
         return self.ws[lane][1]
 
@@ -438,7 +445,16 @@ class NovaEngine(object):
         m.mask_embed.pred_ids = order.unsqueeze(-1)
         noise_fn = inputs.get("noise_fn", None)  # test hook: replay recorded per-step noise (index: running AR step)
         noise_buf = torch.empty(g_B, C, H, W, dtype=_F32, device=rng_dev)
-        to_rows = lambda t: t.to(dev).reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P)
+        # The rows handed to the lanes must OWN their memory. With patch size 1 (point sets) the patchify below is a pure view, and with
+        # a device generator `t` is a slice of `noise_buf`, which the next AR step's draw overwrites on the main stream while a lane
+        # stream may still be waiting to read this step's rows (the host runs a whole encoder pass ahead of the device): the lanes
+        # then denoise from another step's draw, timing-dependently - same distribution, but not the seed's sequence, and not the same
+        # from run to run. `.contiguous()` of the strided view is the copy that cuts the alias (0.8 MB per AR step at batch 32).
+        def to_rows(t):
+            r = t.to(dev).reshape(B, C, h, p, w, p).permute(0, 2, 4, 3, 5, 1).reshape(B, N, P)
+            if not r.is_contiguous():
+                return r.contiguous()  # strided view (patch size 1): the copy
+            return r.clone() if r.data_ptr() == t.data_ptr() else r  # a contiguous view of `t` itself (one channel): copy as well
 
         def draw(i):
             """Per-AR-step draws: x_T canvas [B,N,P] and, for an ancestral sampler, one gaussian canvas per step with t > 0."""

@@ -207,6 +207,38 @@ def test_full_size_pipeline_properties(hip):
     assert (a[0] - a[1]).abs().max() > 1e-3
 
 
+def test_device_generator_draws_reach_their_own_ar_step(hip):
+    """A DEVICE generator (what bench.py and a GPU caller pass) at the point-set geometry (patch size 1), real depth, uneven lanes:
+    the result must be the one obtained by injecting the same draw sequence (order from the first uniform, one normal per AR step),
+    on the very first call of a fresh pipeline and for 1 and 2 lanes alike. Regression test: the per-step noise rows used to alias
+    the engine's reusable draw buffer (the patchify is a pure view at patch size 1), which the next step's draw overwrote on the main
+    stream while the lanes - a whole encoder pass behind the host - had not read them yet; a host generator never showed it."""
+    import bench
+
+    B, C, H, W, K, S = 3, 3, 32, 64, 6, 3
+    dev = torch.device("cuda")
+    prompts = bench.synthetic_prompts(B, dev, torch.bfloat16, seed=7)
+
+    def call(pipe, lanes, **kw):
+        out = pipe(prompt_embeds=prompts, num_inference_steps=K, num_diffusion_steps=S, guidance_scale=5, output_type="latent",
+                   disable_progress_bar=True, lanes=lanes, **kw).frames
+        torch.cuda.synchronize()
+        return out.float().cpu()
+
+    # the draw sequence of generate() for this seed, taken with a second generator: uniform [B, N, 1], then normal [B, C, H, W] per step
+    g = torch.Generator(device=dev).manual_seed(3)
+    order = torch.empty(B, H * W, 1, device=dev).uniform_(generator=g).argsort(dim=1)[..., 0]
+    noises = [torch.empty(B, C, H, W, device=dev).normal_(generator=g).clone() for _ in range(K)]
+    pipe = bench.build_pipeline(1024, 16, H, W, torch.bfloat16, dev)
+    first = call(pipe, 2, generator=torch.Generator(device=dev).manual_seed(3))  # first call of the pipeline, two uneven lanes (1 + 2)
+    injected = call(pipe, 2, pred_order=order, noise_fn=lambda i: noises[i])
+    assert torch.isfinite(first).all()
+    assert torch.equal(first, injected), (first - injected).abs().max().item()
+    one_lane = call(pipe, 1, generator=torch.Generator(device=dev).manual_seed(3))
+    again = call(pipe, 2, generator=torch.Generator(device=dev).manual_seed(3))
+    assert torch.equal(one_lane, first) and torch.equal(again, first)
+
+
 @pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("D,heads", [(768, 12), (1024, 16)])
 def test_small_batch_decoder_fusions_bitwise_and_against_oracle(hip, D, heads, dtype):
