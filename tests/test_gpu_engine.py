@@ -239,6 +239,32 @@ def test_device_generator_draws_reach_their_own_ar_step(hip):
     assert torch.equal(one_lane, first) and torch.equal(again, first)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_runs_reassemble_the_unsharded_batch_on_the_gpu(hip, world):
+    """The seed contract of the multi-GPU path (sharding.py) on the HIP engine itself, one GPU standing in for
+    the ranks one after the other: every 'rank' seeds a DEVICE generator identically, generates its contiguous block of the global
+    prompt list (ragged: 5 prompts over 2 or 3 ranks) with `batch_shard`, and the blocks put together are bit for bit the unsharded
+    run - draws are made for the global batch and sliced, and no kernel's result depends on a row's batch mates. (The exchange itself,
+    one all-gather, is covered with gloo in tests/test_distributed_cpu.py and with one RCCL rank in test_gpu_train_kernels.py.)"""
+    import bench
+    from nova_pointcloud_amd.sharding import generate_sharded, shard_range
+
+    dev = torch.device("cuda")
+    G = 5
+    pipe = bench.build_pipeline(768, 12, 32, 32, torch.bfloat16, dev)
+    prompts = bench.synthetic_prompts(G, dev, torch.bfloat16, seed=11)
+    kw = dict(num_inference_steps=5, num_diffusion_steps=3, guidance_scale=5)
+    whole = generate_sharded(pipe, prompts, 0, 1, generator=torch.Generator(device=dev).manual_seed(17), **kw)
+    assert whole.shape == (G, 32 * 32, 3) and torch.isfinite(whole).all()
+    parts = []
+    for rank in range(world):
+        lo, hi = shard_range(G, rank, world)
+        part = generate_sharded(pipe, prompts, rank, world, generator=torch.Generator(device=dev).manual_seed(17), **kw)
+        assert part.shape[0] == hi - lo  # no process group here: the rank's own rows come back
+        parts.append(part)
+    assert torch.equal(torch.cat(parts), whole)
+
+
 @pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("D,heads", [(768, 12), (1024, 16)])
 def test_small_batch_decoder_fusions_bitwise_and_against_oracle(hip, D, heads, dtype):
