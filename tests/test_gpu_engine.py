@@ -239,6 +239,32 @@ def test_device_generator_draws_reach_their_own_ar_step(hip):
     assert torch.equal(one_lane, first) and torch.equal(again, first)
 
 
+def test_long_lived_pipeline_through_changing_shapes_equals_fresh_pipelines(hip):
+    """A serving loop: ONE pipeline object takes calls of changing batch size, step counts, guidance mode, images per prompt and lane
+    count, issued back to back without a device wait in between (lane workspaces are re-planned, captured graphs dropped and
+    re-captured, lane streams reused while the previous call is still running). Every result is bit for bit what a fresh pipeline gives
+    for the same call (d48w768 at the real depth, bf16, device generator)."""
+    import bench
+
+    dev = torch.device("cuda")
+
+    def call(pipe, B, K, S, guidance=5.0, **kw):
+        return pipe(prompt_embeds=bench.synthetic_prompts(B, dev, torch.bfloat16, seed=5), num_inference_steps=K, num_diffusion_steps=S,
+                    guidance_scale=guidance, generator=torch.Generator(device=dev).manual_seed(9), output_type="latent",
+                    disable_progress_bar=True, **kw).frames
+
+    calls = [dict(B=4, K=5, S=3), dict(B=2, K=5, S=3), dict(B=6, K=4, S=2), dict(B=7, K=6, S=3, guidance=1.0),
+             dict(B=3, K=5, S=3, num_images_per_prompt=2), dict(B=9, K=5, S=3, lanes=3), dict(B=4, K=5, S=3)]
+    served = bench.build_pipeline(768, 12, 32, 32, torch.bfloat16, dev)
+    outs = [call(served, **a) for a in calls]  # enqueued back to back
+    torch.cuda.synchronize()
+    for a, got in zip(calls, outs):
+        want = call(bench.build_pipeline(768, 12, 32, 32, torch.bfloat16, dev), **a)
+        assert torch.isfinite(got.float()).all(), a
+        assert torch.equal(got, want), (a, (got.float() - want.float()).abs().max().item())
+    assert torch.equal(outs[0], outs[-1])  # the same call again at the end of the sequence
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_runs_reassemble_the_unsharded_batch_on_the_gpu(hip, world):
     """The seed contract of the multi-GPU path (sharding.py) on the HIP engine itself, one GPU standing in for
@@ -598,6 +624,16 @@ def test_multi_frame_three_pass_at_full_width_matches_oracle(hip):
     pipe16 = NOVAPipeline(transformer=model.to(torch.bfloat16), scheduler=FlowMatchEulerDiscreteScheduler())
     x16 = pipe16(prompt_embeds=[p.cuda().bfloat16() for p in prompts], pred_order=order, noise_fn=lambda i: noises[i], **kw).frames
     assert rms_rel(x16.float(), ref) < 4e-2, rms_rel(x16.float(), ref)
+    # multi-frame, DEVICE generator (patch size 1: the per-step noise rows are views of the draw buffer unless the engine copies them):
+    # the draws of frame t's AR steps reach those steps - same result as with the sequence injected, for one lane and for two
+    dev = torch.device("cuda")
+    g3 = torch.Generator(device=dev).manual_seed(8)
+    order_d = torch.empty(B, N, 1, device=dev).uniform_(generator=g3).argsort(dim=1)[..., 0]
+    noises_d = [torch.empty(B, 3, H, W, device=dev).normal_(generator=g3).clone() for _ in range(T * steps)]
+    p16 = [p.cuda().bfloat16() for p in prompts]
+    from_gen = {lanes: pipe16(prompt_embeds=p16, generator=torch.Generator(device=dev).manual_seed(8), lanes=lanes, **kw).frames for lanes in (2, 1)}
+    injected = pipe16(prompt_embeds=p16, pred_order=order_d, noise_fn=lambda i: noises_d[i], lanes=2, **kw).frames
+    assert torch.equal(from_gen[2], injected) and torch.equal(from_gen[1], injected)
 
 
 def test_three_pass_rejects_both_scales(vgold, hip):
