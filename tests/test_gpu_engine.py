@@ -203,7 +203,10 @@ def test_full_size_pipeline_properties(hip):
     assert a.shape == (3, 3, 1, 32, 64) and torch.isfinite(a).all()
     assert torch.equal(a, b)
     single = run([1])
-    assert rms_rel(single, a[1:2]) < 2e-2  # bf16: tile shapes (hence rounding order inside row-independent kernels) are unchanged
+    # no kernel's result depends on a row's batch mates, and the structures chosen by shape (small-M / 128 / 256 tiles, fused or separate
+    # modulate, graph replay) are bit-identical: a sample alone is the sample inside the batch. (Measured up to a batch of 160 in one lane -
+    # 819200 rows, scratch buffers past 2^31 elements and 2^32 bytes - for the first, middle and last samples, round 3.)
+    assert torch.equal(single, a[1:2])
     assert (a[0] - a[1]).abs().max() > 1e-3
 
 
