@@ -128,6 +128,63 @@ def test_bf16_training_step_with_hip_attention_matches_torch_attention(hip):
     print(f"\n[train-attn] loss hip {loss_hip:.5f} torch {loss_pt:.5f}; worst 1 - cos over {len(g_pt)} gradients {worst:.2e}")
 
 
+def test_f32_training_step_with_hip_norms_and_activations_matches_the_torch_composition(hip):
+    """One `train_video` step (transformer_3d.py:79-100) of the golden model in f32 on the GPU, all draws injected: the LayerNorm family
+    and the GELU / SiLU activations on the HIP kernels (forward + backward) against the same step on their torch composition (the attention
+    is torch's in both: the HIP attention is a bf16 kernel). Everything is f32, so the two steps agree closely: loss to 1e-5 relative,
+    every parameter gradient to 2e-4 of its largest entry."""
+    import numpy as np
+
+    from diffnext.schedulers import FlowMatchEulerDiscreteScheduler
+    from golden_util import Golden
+    from nova_pointcloud_amd import autograd as A
+    from test_mirror_cpu import build_from_golden
+
+    gold = Golden("tiny_rope")
+
+    def step(use_hip):
+        model = build_from_golden(gold, torch.float32, "cuda")
+        model.noise_scheduler = FlowMatchEulerDiscreteScheduler()
+        model.train()
+        g = torch.Generator().manual_seed(5)
+        real_rand, real_randn, real_normal = torch.rand, torch.randn, torch.normal
+        torch.rand = lambda *a, **k: real_rand(*a, generator=g).to(k.get("device", "cpu"))
+        torch.randn = lambda *a, **k: real_randn(*a, generator=g).to(device=k.get("device", "cpu"), dtype=k.get("dtype", None))
+        torch.normal = lambda m_, s_, size, **k: real_normal(m_, s_, size, generator=g).to(k.get("device", "cpu"))
+        np.random.seed(11)
+        keep = (A._NORM_ENABLED, A._ACT_ENABLED)
+        before = (A.stats["norm_calls"], A.stats["act_calls"])
+        A._NORM_ENABLED = A._ACT_ENABLED = use_hip
+        try:
+            out = model({"x": gold.t["train/x"].clone().cuda(), "prompt": [p.clone().cuda() for p in gold.prompt_embeds]})
+            out["loss"].backward()
+        finally:
+            torch.rand, torch.randn, torch.normal = real_rand, real_randn, real_normal
+            A._NORM_ENABLED, A._ACT_ENABLED = keep
+        calls = (A.stats["norm_calls"] - before[0], A.stats["act_calls"] - before[1])
+        grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+        return float(out["loss"].detach()), grads, calls
+
+    loss_hip, g_hip, n_hip = step(True)
+    loss_pt, g_pt, n_pt = step(False)
+    assert n_hip[0] > 0 and n_hip[1] > 0 and n_pt == (0, 0), (n_hip, n_pt)
+    assert abs(loss_hip - loss_pt) <= 1e-5 * abs(loss_pt), (loss_hip, loss_pt)
+    assert g_hip.keys() == g_pt.keys() and len(g_hip) > 20
+    worst = 0.0
+    for name, ref in g_pt.items():
+        got = g_hip[name]
+        assert torch.isfinite(got).all(), name
+        scale = float(ref.abs().max())
+        if scale == 0.0:
+            assert float(got.abs().max()) == 0.0, name
+            continue
+        err = float((got - ref).abs().max()) / scale
+        assert err < 2e-4, (name, err)
+        worst = max(worst, err)
+    print(f"\n[train-f32] loss hip {loss_hip:.7f} torch {loss_pt:.7f}; worst relative gradient error over {len(g_pt)} tensors {worst:.2e}; "
+          f"HIP norm / activation calls {n_hip}")
+
+
 def test_train_script_one_rank_under_torchrun_bf16_on_rccl(hip, tmp_path):
     """`scripts/train.py` as the reference launches it - one process per GPU under torchrun - on this box's one GPU:
     NOVA-d48w768 random-init (the config's architecture), bf16, 64-point synthetic samples, 3 steps. The process group is
