@@ -178,7 +178,7 @@ class NovaEngine(object):
         self.sig = None
         self.fp8 = False
         self.fp8_delayed = True
-        self.ws = {}  # lane -> (shape key, buffers)
+        self.ws = {}  # lane -> {shape key: buffers} in order of last use (see _workspace)
 
     # ------------------------------------------------------------------ packing / workspaces
     @classmethod
@@ -245,12 +245,20 @@ class NovaEngine(object):
     # larger modulation buffer stays under this many bytes per lane (config C: 3.3 GB; 288 GB of HBM per GPU)
     MOD_HOIST_BYTES = 12 << 30
 
+    # A lane keeps the scratch buffers of its last WS_KEEP call shapes (most recent last), as long as all kept buffers stay under
+    # WS_KEEP_FRACTION of the device memory: a serving loop that alternates between a few batch sizes then neither re-allocates nor
+    # re-captures its denoising-loop graphs (their keys hold these buffers' addresses) on every change. Evicting a set drops the graph
+    # cache (nova_debug_drop_graphs waits for the device first: a launch of one of those graphs may still be queued).
+    WS_KEEP = 3
+    WS_KEEP_FRACTION = 0.25
+
     def _workspace(self, S, B, N, L, nmax, lane=0, steps=1):
-        """Scratch buffers of one lane, reallocated only when the shapes (or dtype / fp8 mode) change."""
+        """Scratch buffers of one lane for this call shape (dtype / fp8 mode included): allocated on first use, kept as described above."""
         key = (S, B, N, L, nmax, self.dtype, self.dev, self.fp8, steps)
-        if self.ws.get(lane, (None, None))[0] != key:
-            if lane in self.ws:  # the graphs captured for the old buffers' addresses can never be replayed again: drop them
-                hip.call("nova_debug_drop_graphs")
+        kept = self.ws.setdefault(lane, {})  # shape key -> buffers, in order of last use
+        if key in kept:
+            kept[key] = kept.pop(key)  # most recently used last
+        else:
             D, dt, dev = self.D, self.dtype, self.dev
             e = lambda *shape: torch.empty(*shape, dtype=dt, device=dev)
             rows = S * L
@@ -273,8 +281,21 @@ class NovaEngine(object):
                         v.fill_(float("nan"))
                     elif torch.is_tensor(v):
                         v.fill_(-1 if v.dtype == torch.int64 else 0xFF)
-            self.ws[lane] = (key, ws)
-        return self.ws[lane][1]
+            kept[key] = ws
+            self._evict_workspaces(lane, key)
+        return kept[key]
+
+    def _evict_workspaces(self, lane, keep_key):
+        nbytes = lambda ws: sum(v.numel() * v.element_size() for v in ws.values() if torch.is_tensor(v))
+        budget = self.WS_KEEP_FRACTION * torch.cuda.get_device_properties(self.dev).total_memory
+        dropped = False
+        kept = self.ws[lane]
+        while len(kept) > 1 and (len(kept) > self.WS_KEEP or sum(nbytes(w) for lanes in self.ws.values() for w in lanes.values()) > budget):
+            oldest = next(k for k in kept if k != keep_key)
+            del kept[oldest]
+            dropped = True
+        if dropped:  # graphs captured for the evicted buffers' addresses can never be replayed again
+            hip.call("nova_debug_drop_graphs")
 
     # ------------------------------------------------------------------ building blocks
     def _blocks(self, pack, x, S, L, rope, rope_batch, ws):

@@ -266,6 +266,21 @@ def test_long_lived_pipeline_through_changing_shapes_equals_fresh_pipelines(hip)
         assert torch.isfinite(got.float()).all(), a
         assert torch.equal(got, want), (a, (got.float() - want.float()).abs().max().item())
     assert torch.equal(outs[0], outs[-1])  # the same call again at the end of the sequence
+    # alternating between two call shapes: each lane keeps the scratch buffers (hence the captured graphs) of its last few shapes, so
+    # from the second visit on nothing is captured again
+    from nova_pointcloud_amd.engine import NovaEngine
+
+    alt = [dict(B=4, K=5, S=3), dict(B=2, K=5, S=3)]
+    for a in alt:
+        call(served, **a)
+    torch.cuda.synchronize()
+    captured, replayed = hip.graph_stats()
+    again = [call(served, **a) for a in alt * 2]
+    torch.cuda.synchronize()
+    assert hip.graph_stats()[0] == captured and hip.graph_stats()[1] > replayed
+    assert torch.equal(again[0], outs[0]) and torch.equal(again[1], outs[1]) and torch.equal(again[2], outs[0])
+    eng = NovaEngine.for_model(served.transformer)
+    assert all(len(kept) <= eng.WS_KEEP for kept in eng.ws.values())
     # the caller's own stream: the call is issued under a side stream and consumed there without an explicit wait (the lanes fork from
     # and join the caller's stream, whichever it is)
     side = torch.cuda.Stream()
