@@ -145,3 +145,22 @@ def test_prefilled_first_frame_matches_reference(vgold):
     ref = vgold.t["out/x_prefilled"]
     assert x.shape == ref.shape and torch.equal(x[:, :, 0], first)
     assert (x - ref).abs().max() <= 2e-5 * ref.abs().max()
+
+
+def test_stored_schedule_oracle_outputs_are_well_formed():
+    """tests/golden/schedule_oracle_<case>.npz (made by make_golden_schedule_oracle.py: the oracle's output for the full-schedule parity
+    cases of test_gpu_parity_full.py): plain arrays (loadable without pickle), finite latents of the case's shape, the seeds the GPU test's
+    fixture uses."""
+    import glob
+    import os
+
+    import numpy as np
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule_oracle_*.npz")))
+    assert len(files) >= 2
+    for path in files:
+        z = np.load(path, allow_pickle=False)
+        width, heads, H, W, B, K, S = (int(v) for v in z["params"])
+        assert z["ref"].shape == (B, 3, 1, H, W) and z["ref"].dtype == np.float32 and np.isfinite(z["ref"]).all()
+        assert [int(v) for v in z["seeds"]] == [0, 4321, 29] and (K, S) == (64, 25) and width % heads == 0
+        assert 1.0 < float(np.abs(z["ref"]).max()) < 10.0  # latents of a flow-matching sampler started from N(0, 1)
