@@ -747,7 +747,9 @@ class NovaEngine(object):
                     step_noise = torch.stack([torch.zeros(B, n, P, dtype=_F32, device=dev) if e is None else e.gather(1, idx)
                                               for e in extra]).contiguous()
                 if renorm < 1 and cfg_on:  # squared norm of the rows that only echo x_t in the reference (guidance_scaler.py:67-72)
-                    echo = (nz.pow(2).sum((1, 2)) - x_n.pow(2).sum((1, 2))).clamp_min(0).contiguous()
+                    # per-sample sums in float64: an f32 reduction's summation order follows the tensor's batch size (torch tiles it by shape),
+                    # which would make a sample's result depend - at rounding level - on how many samples share its lane
+                    echo = (nz.double().pow(2).sum((1, 2)) - x_n.double().pow(2).sum((1, 2))).clamp_min(0).float().contiguous()
                     ws_v = torch.empty(3 * B * n * P, dtype=_F32, device=dev)
                 hip.call("nova_decoder_denoise", ctypes.byref(self.dec.struct), zc.data_ptr(), temb.data_ptr(), x_n.data_ptr(), plan,
                          hip.ptr(step_noise), renorm if cfg_on else 1.0, hip.ptr(echo), steps, S, B, n, P, D, ws["da"].data_ptr(),
