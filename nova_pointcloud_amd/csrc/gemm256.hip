@@ -525,7 +525,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
 #pragma unroll
         for (int mf = 0; mf < 8; ++mf) acc[nf][mf] = (acc[nf][mf] * sav[mf]) * swv[nf] + bfv[nf];
     }
-    f4v cs[4][2][4];  // [group][row block][nf]
+#ifdef NOVA_ROPE_HALF_TABLE  // timing-only experiment (tools/ab_lib.py, never shipped): the cos / sin table read as f16 - half the bytes, half the registers
+    typedef u2v CsT;
+#else
+    typedef f4v CsT;
+#endif
+    CsT cs[4][2][4];  // [group][row block][nf]
     int coff[4];      // column of this lane's 4 floats inside a table row (head-relative), per nf
     if (rot) {
 #pragma unroll
@@ -543,9 +548,15 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
         int l = l0 + min(fr, M - 1 - mb);  // rows past M reuse row M-1 (never stored differently)
         int sb = b0;
         if (l >= e.L) { l -= e.L; sb = b1; }  // a 16-row block crosses at most one sequence boundary (L >= 16)
+#ifdef NOVA_ROPE_HALF_TABLE
+        const uint16_t* roph = reinterpret_cast<const uint16_t*>(e.rope) + ((size_t)sb * e.L + l) * e.hd;
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) cs[g][j][nf] = *reinterpret_cast<const u2v*>(roph + coff[nf]);
+#else
         const float* ropem = e.rope + ((size_t)sb * e.L + l) * e.hd;
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) cs[g][j][nf] = *reinterpret_cast<const f4v*>(ropem + coff[nf]);
+#endif
       }
     };
     float q8_inv = 1.0f, q8_max = 0.f;
@@ -596,7 +607,12 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
             for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
           } else if (EPI == E_ROPE) {
             if constexpr (ROT) {
+#ifdef NOVA_ROPE_HALF_TABLE
+              const f2v ta = Half16<f16_t>::unpack(cs[g][j][nf][0]), tb = Half16<f16_t>::unpack(cs[g][j][nf][1]);
+              v = rope_rotate4(v, f4v{ta[0], ta[1], tb[0], tb[1]});
+#else
               v = rope_rotate4(v, cs[g][j][nf]);
+#endif
             }
             v = v * qmul;
           }
