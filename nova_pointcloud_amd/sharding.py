@@ -24,30 +24,37 @@ def shard_list(items, rank, world):
     return list(items[lo:hi])
 
 
-def gather_points(points, group=None):
+def gather_points(points, group=None, total=None, per=1):
     """All-gather [B_loc, N, 3] point sets of every rank into [sum B_loc, N, 3] (rank order).
 
-    Equal shard sizes use one `all_gather_into_tensor`; ragged shards are padded to the largest.
+    `total` = number of items (prompts) sharded over the ranks, `per` samples each (`num_images_per_prompt`): every rank's
+    shard size then follows from `shard_range` and the path's
+    one collective is issued without a size exchange or a host read-back (nothing between the pipeline's last kernel and the
+    all-gather waits for the device). Equal shards use one `all_gather_into_tensor`; ragged shards are padded to the
+    largest. Without `total` the shards must be equal-sized (checked against the gathered tensor's shape only).
     """
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized():  # with a process group the exchange runs, also for one rank
         return points
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     points = points.contiguous()
-    sizes = torch.tensor([points.shape[0]], dtype=torch.int64, device=points.device)
-    all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
-    counts = [int(s.item()) for s in all_sizes]
+    if total is None:
+        counts = [points.shape[0]] * world
+    else:
+        counts = [(hi - lo) * per for lo, hi in (shard_range(total, r, world) for r in range(world))]
+        if counts[rank] != points.shape[0]:
+            raise ValueError(f"rank {rank} holds {points.shape[0]} samples, shard_range({total}, {rank}, {world}) says {counts[rank]}")
     if len(set(counts)) == 1:
         out = points.new_empty((world * counts[0],) + tuple(points.shape[1:]))
         dist.all_gather_into_tensor(out, points, group=group)
         return out
     pad = points.new_zeros((max(counts),) + tuple(points.shape[1:]))
     pad[: points.shape[0]] = points
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:n] for p, n in zip(parts, counts)])
+    out = pad.new_empty((world * max(counts),) + tuple(points.shape[1:]))
+    dist.all_gather_into_tensor(out, pad, group=group)
+    parts = out.view(world, max(counts), *points.shape[1:])
+    return torch.cat([parts[r, :n] for r, n in enumerate(counts)])
 
 
 def generate_sharded(pipe, prompt_embeds, rank, world, group=None, **call_kwargs):
@@ -60,4 +67,4 @@ def generate_sharded(pipe, prompt_embeds, rank, world, group=None, **call_kwargs
     lo, hi = shard_range(len(prompt_embeds), rank, world)
     out = pipe(prompt_embeds=list(prompt_embeds[lo:hi]), output_type="latent", disable_progress_bar=True,
                batch_shard=(lo * per, hi * per, len(prompt_embeds) * per), **call_kwargs)
-    return gather_points(points_from_latents(out.frames).float().contiguous(), group)
+    return gather_points(points_from_latents(out.frames).float().contiguous(), group, total=len(prompt_embeds), per=per)

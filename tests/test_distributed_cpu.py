@@ -16,6 +16,15 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
 from nova_pointcloud_amd.sharding import shard_range  # noqa: E402
 
 
+def free_port():
+    """A TCP port nobody listens on right now (rendezvous of the spawned ranks on 127.0.0.1)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_shard_range_covers_everything():
     for total in (0, 1, 7, 32, 33):
         for world in (1, 2, 3, 8):
@@ -60,7 +69,7 @@ def test_two_rank_sharded_generation_equals_unsharded_run_of_the_same_seed(ragge
 
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if ragged else 0)
+    port = free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, ragged, ret)) for r in range(2)]
     [p.start() for p in procs]
     got = ret.get(timeout=300)
@@ -81,27 +90,64 @@ def test_two_rank_sharded_generation_equals_unsharded_run_of_the_same_seed(ragge
         assert (ref - gx).abs().max() <= 1e-4 * gx.abs().max()
 
 
-@pytest.mark.parametrize("global_batch", [0, 3])
-def test_bench_launch_contract_two_ranks_dry_run(global_batch):
-    """The driver's N > 1 launch line, rehearsed on CPU (gloo): rendezvous, per-rank shard, gather, max-over-ranks timing; the
-    JSON line carries what the process group itself saw (`ranks_seen`), each rank's block of the global prompt list
-    (`shards`: [rank, lo, hi), incl. a ragged global batch of 3 over 2 ranks), and rank 0's check that the gathered rows are
-    the unsharded run's samples in prompt order."""
+def _gather_worker(rank, world, port, total, per, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nova_pointcloud_amd.sharding import gather_points
+
+    lo, hi = shard_range(total, rank, world)
+    mine = torch.arange(lo * per, hi * per, dtype=torch.float32).view(-1, 1, 1).expand(-1, 5, 3).contiguous()
+    out = gather_points(mine, total=total, per=per)
+    bad = None
+    try:  # a rank whose row count contradicts shard_range is an error, not a silent mis-assembly
+        gather_points(mine[:-1] if mine.shape[0] else mine.new_zeros(1, 5, 3), total=total, per=per)
+    except ValueError as e:
+        bad = str(e)
+    if rank == 0:
+        ret.put((out, bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total,per", [(3, 7, 2), (4, 8, 1), (3, 2, 1)])
+def test_gather_points_sizes_come_from_shard_range(world, total, per):
+    """The path's only collective (the reference's rank-strided precedent: evaluations/geneval/sample.py:55,70)
+    is issued without a size exchange: every rank derives all shard sizes from `shard_range` (ragged shards, several samples
+    per prompt, a rank with no prompt at all), pads to the largest and gathers into one tensor."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, total, per, ret)) for r in range(world)]
+    [p.start() for p in procs]
+    out, bad = ret.get(timeout=120)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert out.shape == (total * per, 5, 3)
+    assert torch.equal(out[:, 0, 0], torch.arange(total * per, dtype=torch.float32))
+    assert bad is not None and "shard_range" in bad
+
+
+@pytest.mark.parametrize("world,global_batch", [(2, 0), (2, 3), (4, 6), (8, 11)])
+def test_bench_launch_contract_dry_run(world, global_batch):
+    """The driver's N > 1 launch line, rehearsed on CPU (gloo) with 2, 4 and 8 ranks: rendezvous, per-rank shard, gather,
+    max-over-ranks timing; the JSON line carries what the process group itself saw (`ranks_seen`), each rank's block of the global
+    prompt list (`shards`: [rank, lo, hi), incl. ragged global batches: 3 over 2, 6 over 4, 11 over 8 ranks), and rank 0's check
+    that the gathered rows are the unsharded run's samples in prompt order."""
     import json
     import subprocess
 
-    port = 29700 + (os.getpid() % 200) + global_batch
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "1",
            "--cpu-dry-run", "--workload", "d48w768_256pts_b1", "--ar-steps", "2", "--diffusion-steps", "2",
            "--global-batch", str(global_batch)]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout  # exactly one JSON line, from rank 0
     rec = json.loads(lines[0])
-    G = global_batch or 2
-    assert rec["n_gpus"] == 2 and rec["points"] == [G, 256, 3]
-    assert rec["ranks_seen"] == [0, 1]
-    assert rec["shards"] == ([[0, 0, 1], [1, 1, 2]] if G == 2 else [[0, 0, 2], [1, 2, 3]])
+    G = global_batch or world
+    assert rec["n_gpus"] == world and rec["points"] == [G, 256, 3]
+    assert rec["ranks_seen"] == list(range(world))
+    assert rec["shards"] == [[r, *shard_range(G, r, world)] for r in range(world)]
+    assert [hi - lo for _, lo, hi in rec["shards"]].count(0) == 0 and sum(hi - lo for _, lo, hi in rec["shards"]) == G
     assert rec["sharded_vs_unsharded_max_rel_diff"] < 1e-4

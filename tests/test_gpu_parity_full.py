@@ -185,3 +185,63 @@ def test_fp8_gemm_mode_against_bf16_and_oracle_at_full_depth(case, hip):
     e_bf16, e_ref = rms_rel(x8, x16), rms_rel(x8, case["ref"])
     print(f"\n[parity-full] {case['name']} fp8 GEMMs: rms rel vs bf16 {e_bf16:.3e}, vs f32 oracle {e_ref:.3e}")
     assert e_bf16 < 0.12, e_bf16  # measured 7.0-7.6e-2
+
+
+def test_benchmarked_workload_batch32_is_its_batch1_samples_and_the_oracle_case(hip):
+    """The workload `bench.py` times - BASELINE configs[2]: NOVA-d48w1024, 2048 points, batch 32, 64 AR x 25 diffusion steps, bf16,
+    a DEVICE generator, two half-batch lanes (256-tile GEMMs at M = 163840, the hoisted AdaLN buffer, graph-replayed denoising
+    loops) - run inside the suite and tied to the oracle (transformer_3d.py:115-133):
+      (a) the bench's own call (its prompts, its generator seed) gives, for samples 0 / 15 / 16 / 31 (first and last of either
+          lane), bit for bit the points the same prompt gives ALONE at batch 1 under the same draws (injected from a second
+          generator with the same seed: uniform [B, N, 1] first, then one normal [B, C, H, W] per AR step);
+      (b) with the stored oracle case's prompt and draws in slot 0 (tests/golden/schedule_oracle_headline_full_*.npz: weights from
+          seed 0 = the bench's, prompt from seed 4321, host generator 29), sample 0 of the batch of 32 is bit for bit that case
+          run alone, within the bf16 bound of the oracle's output, and the other 31 samples are unchanged from (a)."""
+    import numpy as np
+
+    import bench
+
+    name = "headline_full_d48w1024_2048pts_K64S25"
+    path = stored_oracle(name)
+    if path is None:
+        pytest.skip("stored oracle output of the headline case is not in tests/golden")
+    width, heads, H, W, B = bench.WORKLOADS["d48w1024_2048pts_b32"]
+    N, K, S = H * W, 64, 25
+    dev = torch.device("cuda")
+    z = np.load(path)
+    assert [int(v) for v in z["params"]] == [width, heads, H, W, 1, K, S] and [int(v) for v in z["seeds"]] == [0, 4321, 29]
+    ref = torch.from_numpy(z["ref"])  # [1, 3, 1, H, W]
+    pipe = bench.build_pipeline(width, heads, H, W, torch.bfloat16, dev)  # weights: torch.manual_seed(0), as the stored case's
+    prompts = bench.synthetic_prompts(B, dev, torch.bfloat16, seed=1234)  # bench.py's prompts
+
+    def call(prm, **kw):
+        out = pipe(prompt_embeds=prm, num_inference_steps=K, num_diffusion_steps=S, guidance_scale=5, output_type="latent",
+                   disable_progress_bar=True, **kw).frames
+        return out
+
+    # (a) bench.py's call
+    got = call(prompts, generator=torch.Generator(device=dev).manual_seed(0))
+    g = torch.Generator(device=dev).manual_seed(0)
+    order = torch.empty(B, N, 1, device=dev).uniform_(generator=g).argsort(dim=1)[..., 0]
+    n_steps = len([v for v in O.cosine_schedule(N, K) if v > 0])
+    noises = [torch.empty(B, 3, H, W, device=dev).normal_(generator=g).clone() for _ in range(n_steps)]
+    torch.cuda.synchronize()
+    assert got.shape == (B, 3, 1, H, W) and torch.isfinite(got.float()).all()
+    for i in (0, 15, 16, 31):
+        alone = call([prompts[i]], pred_order=order[i:i + 1], noise_fn=lambda s, i=i: noises[s][i:i + 1])
+        assert torch.equal(alone, got[i:i + 1]), (i, (alone.float() - got[i:i + 1].float()).abs().max().item())
+    # (b) the oracle case in slot 0
+    hg = torch.Generator().manual_seed(29)
+    u0 = torch.empty(1, N, 1).uniform_(generator=hg)
+    n0 = [torch.empty(1, 3, H, W).normal_(generator=hg) for _ in range(n_steps)]
+    p0 = bench.synthetic_prompts(1, dev, torch.bfloat16, seed=4321)
+    order_b = torch.cat([u0.argsort(dim=1)[..., 0].to(dev), order[1:]])
+    noises_b = [torch.cat([n0[s].to(dev), noises[s][1:]]) for s in range(n_steps)]
+    mixed = call(p0 + prompts[1:], pred_order=order_b, noise_fn=lambda s: noises_b[s])
+    alone0 = call(p0, pred_order=order_b[:1], noise_fn=lambda s: noises_b[s][:1])
+    torch.cuda.synchronize()
+    assert torch.equal(mixed[1:], got[1:])
+    assert torch.equal(mixed[:1], alone0)
+    err = rms_rel(mixed[:1].float(), ref)
+    print(f"\n[parity-full] batch-32 headline workload, sample 0 = stored oracle case: bf16 rms rel {err:.3e}")
+    assert err < FULL_SCHEDULE[name][7], err
