@@ -17,8 +17,8 @@
  *     thread-local message for the last failure. Nothing throws.
  *   - dtype: storage type of activations and GEMM weights (NOVA_F32 = parity mode on exact-f32
  *     MFMA, NOVA_BF16 / NOVA_F16 = throughput mode on the bf16 / f16 MFMA forms - same kernels, same rate; f16 is the
- *     default precision of the reference's callers, scripts/app_nova_t2i.py:36,87-89. The fp8 GEMM mode and the training
- *     (backward) entries take bf16 only). Biases, LayerNorm affine parameters, RoPE
+ *     default precision of the reference's callers, scripts/app_nova_t2i.py:36,87-89. The fp8 GEMM mode and the attention backward take bf16 only;
+ *     nova_row_norm_bwd and nova_act_fwd / nova_act_bwd take all three). Biases, LayerNorm affine parameters, RoPE
  *     tables, point coordinates, timesteps and sigmas are always float32; token ids are int64
  *     (torch.long, as the reference's pred_ids / prev_ids).
  *   - row-major everywhere; a "row" is one token's feature vector.
@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NOVA_HIP_VERSION 300 /* 0.3.0: NOVA_F16 storage mode through every dtype-taking entry, nova_row_norm_chain takes a dtype, nova_debug_set_attn_variant; 0.2.2: nova_attn_fwd_lse, nova_attn_bwd; 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
+#define NOVA_HIP_VERSION 400 /* 0.4.0 (round 4): the loader checks this number against its own; nova_attn_fwd_lse / nova_attn_bwd carry a key_limit pointer before the stream, nova_row_norm_bwd, nova_act_fwd, nova_act_bwd, nova_debug_drop_graphs (all added after 0.3.0 without a bump), nova_prof slots 7-9; 0.3.0: NOVA_F16 storage mode through every dtype-taking entry, nova_row_norm_chain takes a dtype, nova_debug_set_attn_variant; 0.2.2: nova_attn_fwd_lse, nova_attn_bwd; 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
 
 typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1, NOVA_F16 = 2 } nova_dtype;
 typedef enum { NOVA_ACT_NONE = 0, NOVA_ACT_GELU_ERF = 1, NOVA_ACT_SILU = 2 } nova_act;

@@ -162,6 +162,9 @@ class NovaFusedNormFunction(torch.autograd.Function):
         hip.load()
         stats["norm_calls"] += 1
         shape, D = x.shape, x.shape[-1]
+        for name, t in (("res", res), ("scale", scale), ("shift", shift), ("gate", gate)):
+            if t is not None and t.dtype != x.dtype:  # the kernel reads every operand in x's storage type (e.g. autocast: fp16 x, f32 res)
+                raise TypeError(f"fused_norm: {name} is {t.dtype}, x is {x.dtype} (see fused_norm_supported)")
         x2 = x.reshape(-1, D).contiguous()
         rows = x2.shape[0]
         mods = {k: t for k, t in (("scale", scale), ("shift", shift), ("gate", gate)) if t is not None}

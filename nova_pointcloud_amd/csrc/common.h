@@ -172,10 +172,15 @@ __device__ __forceinline__ f4v gelu_erf_fast4(f4v x) {
 
 // RoPE rotation of the two adjacent pairs a lane holds of one accumulator fragment (embeddings.py:36-43): (x0, x1) -> (c0 x0 - s0 x1,
 // s0 x0 + c0 x1), likewise (x2, x3) with (c1, s1); t = (c0, s0, c1, s1). One function for every GEMM epilogue, so the tile
-// structures stay bit-identical. (A v_pk_mul_f32 + v_pk_fma_f32 form with op_sel / neg_lo modifiers - half the issues - measured
-// SLOWER in the persistent kernel: rotate / no-rotate time ratio 1.146 against 1.107 for this scalar form, round 3.)
+// structures stay bit-identical - and with the roundings WRITTEN OUT: each output is one product rounded to f32 and one fused
+// multiply-add on top of it. Left to the compiler (fp-contract is on by default), which of the two products of `a b - c d` is fused
+// depends on the code around the call, and two kernels inlining the same source line can round differently (round 4: the rewritten
+// 256-tile epilogue no longer matched the 128-tile kernel bit for bit).
+// (A v_pk_mul_f32 + v_pk_fma_f32 form with op_sel / neg_lo modifiers - half the issues - measured SLOWER in the persistent
+// kernel: rotate / no-rotate time ratio 1.146 against 1.107 for the scalar form, round 3.)
 __device__ __forceinline__ f4v rope_rotate4(f4v x, f4v t) {
-  return f4v{t[0] * x[0] - t[1] * x[1], t[1] * x[0] + t[0] * x[1], t[2] * x[2] - t[3] * x[3], t[3] * x[2] + t[2] * x[3]};
+  return f4v{__builtin_fmaf(t[0], x[0], -__fmul_rn(t[1], x[1])), __builtin_fmaf(t[1], x[0], __fmul_rn(t[0], x[1])),
+             __builtin_fmaf(t[2], x[2], -__fmul_rn(t[3], x[3])), __builtin_fmaf(t[3], x[2], __fmul_rn(t[2], x[3]))};
 }
 
 // XCD-aware, bijective remap of a 1-D block id: blocks that share an XCD (id % 8) get a

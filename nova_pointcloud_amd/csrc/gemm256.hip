@@ -9,21 +9,33 @@
 // its 16 MFMAs of a phase, the other group issues its LDS fragment reads and the next LDS-DMA prefetch, then they
 // swap. LDS-DMA stays in flight across barriers under a counted s_waitcnt vmcnt (never 0 in the loop).
 //
+// Operand roles (round 4). The tile is computed as P[x][y] = sum_k X[x][k] Y[y][k] with X = 256 rows of W (output COLUMNS,
+// split over the two wave groups wr) and Y = 256 rows of A (output ROWS, split over wc = 0..3); Y fragments are the MFMA's
+// first operand, so a lane (j = lane & 15, fg = lane >> 4) holds, per accumulator, output rows 4 fg + {0,1,2,3} of ONE
+// column j. Which W row sits at fragment row j is free (it is only the LDS-DMA source address), two maps are used:
+//   COLS8 (every epilogue but RoPE): X fragment f of half xi takes W rows 8 j + 4 xi + f - a lane's eight X fragments are 8
+//     CONSECUTIVE columns, one 16-byte store per output row (16-bit types), 4 rows x 256 contiguous bytes per store instruction;
+//   COLS4 (RoPE): X fragment f of half xi takes W rows 64 xi + 4 j + f - 4 consecutive columns per half, so the 16 lanes j read
+//     one table row's 64 floats as 256 contiguous bytes, ONE 16-byte table load per output row serves both halves when the
+//     head width divides 64, and stores are 8 bytes per lane (4 rows x 128 contiguous bytes per instruction). Rounds 1-3 had the roles the other way round (a lane = one
+// row, 4 columns per fragment): adjacent lanes then sat in different rows, the memory pipeline took such a store or load
+// one LANE at a time (tools/ta_probe.hip: 67 against 31 cycles per 16-byte store instruction, 22 per 8-byte one), and the epilogue's 16 stores + 32 table
+// loads per lane were most of the K = 1024 tiles' seam. Same MFMA, same k order: results are bit-identical to gemm.hip.
+//
 // Phase plan. A K-tile (64 bf16 / 32 f32 per row) is staged as 4 units of 128 rows x 128 B:
-//   A(mi): rows {wr*128 + mi*64 + [0,64)}  of the A tile, for both wr      (read in phase 0 / 2)
-//   W(ni): rows {wc*64  + ni*32 + [0,32)}  of the W tile, for all four wc  (read in phase 0 / 1)
-// A wave (wr, wc) owns out[wr*128 + 128][wc*64 + 64] = 8 x 4 MFMA 16x16 fragments. Per K-tile, 4 phases:
-//   p0: read A(0), W(0) -> quadrant (0,0)   p1: read W(1) -> (0,1)   p2: read A(1) -> (1,1)
-//   p3: no LDS reads, quadrant (1,0) on the W(0) fragments kept in registers since p0
-// 16 MFMAs each (8 independent accumulators per k-half). Staging order is A0, W1, A1, W0 per tile (flat index
+//   X(xi): W rows {wr*128 + xi*64 + 4 j + f}  as unit row wr*64 + f*16 + j, for both wr       (read in phase 0 / 2)
+//   Y(yi): A rows {wc*64  + yi*32 + [0,32)}  as unit row wc*32 + [0,32), for all four wc     (read in phase 0 / 1)
+// A wave (wr, wc) owns out[wc*64 + 64 rows][wr*128 + 128 columns] = 4 (Y) x 8 (X) MFMA 16x16 fragments. Per K-tile, 4 phases:
+//   p0: read X(0), Y(0) -> quadrant (0,0)   p1: read Y(1) -> (0,1)   p2: read X(1) -> (1,1)
+//   p3: no LDS reads, quadrant (1,0) on the Y(0) fragments kept in registers since p0
+// 16 MFMAs each (8 independent accumulators per k-half). Staging order is X0, Y1, X1, Y0 per tile (flat index
 // q = 4*tile + unit); phase p of tile t issues q = 4t + p + 6, i.e. always the unit whose LDS slot (2 K-tile
 // buffers x 4 units = 128 KiB) had its last read at least TWO phases earlier - the distance that is safe for
 // groups running one barrier apart with the fragment-read wait placed after the phase's first barrier.
 // One wait per K-tile: a counted s_waitcnt vmcnt before the first barrier of phase 3 retires everything but the
 // youngest unit(s) (= all of tile t+1); the first read of tile t+1 happens in the next phase, one barrier later.
-// Epilogue: bias/GELU/SiLU/RoPE lane-local as in gemm.hip; bf16 results of two fragments are exchanged with
-// v_permlane16_swap so every lane stores 16 contiguous bytes (half the store instructions of the 8-byte form).
-// Results are bit-identical to gemm.hip (same MFMA, same k order): tests/test_gpu_kernels.py compares them.
+// Epilogue: bias (the accumulators start at it), GELU / SiLU / RoPE pair rotation / q-scale lane-local on the lane's 4
+// consecutive columns, as in gemm.hip. Results are bit-identical to gemm.hip: tests/test_gpu_kernels.py compares them.
 #include <type_traits>
 #include "common.h"
 #include "nova_internal.h"
@@ -31,8 +43,10 @@
 namespace nova {
 
 constexpr int P_UNIT = 128 * 128;   // bytes of one staged unit (128 rows x 128 B)
-constexpr int P_BUF = 4 * P_UNIT;   // A(0) A(1) W(0) W(1)
-constexpr int P_LDS = 2 * P_BUF;    // 128 KiB
+constexpr int P_BUF = 4 * P_UNIT;   // X(0) X(1) Y(0) Y(1)
+constexpr int P_KLDS = 2 * P_BUF;   // 128 KiB: two K-tile buffers
+constexpr int P_BIAS = P_KLDS;      // persistent form: the tile's 256 bias values (1 KiB), brought in by LDS-DMA like the operands
+constexpr int P_LDS = P_KLDS + 1024;
 
 struct GemmEpi;  // same POD as gemm.hip (redeclared below to keep the translation units independent)
 struct GemmEpi256 {
@@ -66,11 +80,12 @@ typedef __attribute__((ext_vector_type(8))) int i8v;
 template <typename T> struct OutOf { typedef T type; };
 template <> struct OutOf<fp8_t> { typedef bf16_t type; };  // fp8 operands produce bf16 results
 
-__device__ __forceinline__ f4v pmma(const PFrag<bf16_t>& w, const PFrag<bf16_t>& a, f4v c) { return Half16<bf16_t>::mfma16(w.v, a.v, c); }
-__device__ __forceinline__ f4v pmma(const PFrag<f16_t>& w, const PFrag<f16_t>& a, f4v c) { return Half16<f16_t>::mfma16(w.v, a.v, c); }
-__device__ __forceinline__ f4v pmma(const PFrag<float>& w, const PFrag<float>& a, f4v c) {
+// first operand: the Y (output row) fragment, second: the X (output column) fragment
+__device__ __forceinline__ f4v pmma(const PFrag<bf16_t>& y, const PFrag<bf16_t>& x, f4v c) { return Half16<bf16_t>::mfma16(y.v, x.v, c); }
+__device__ __forceinline__ f4v pmma(const PFrag<f16_t>& y, const PFrag<f16_t>& x, f4v c) { return Half16<f16_t>::mfma16(y.v, x.v, c); }
+__device__ __forceinline__ f4v pmma(const PFrag<float>& y, const PFrag<float>& x, f4v c) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(w.v[j], a.v[j], c, 0, 0, 0);
+  for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(y.v[j], x.v[j], c, 0, 0, 0);
   return c;
 }
 
@@ -81,8 +96,70 @@ __device__ __forceinline__ PFrag<T> punit_frag(const char* unit, int row, int ch
   return f;
 }
 
+// Per-lane byte offsets (from the tile's W / A base) of the two LDS-DMA pieces a wave moves for each staged unit, in staging
+// order u: 0 = X(0), 1 = Y(1), 2 = X(1), 3 = Y(0). Piece i of wave wid fills unit rows (wid*2 + i)*8 + [0, 8), 8 lanes (128 B) per
+// row, the 16-byte chunks in source-swizzled order (punit_frag reads with the same xor). `rmax` = last valid A row of the tile
+// (rows past M re-read row M-1; their results are stored onto row M-1 again, identical bytes).
+template <bool COLS8>
+__device__ __forceinline__ void dma_offsets(int lane, int wid, int rmax, uint32_t rowbytes, uint32_t (&soff)[4][2]) {
+  const int cp = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (wid * 2 + i) * 8 + (lane >> 3);              // row inside the unit, 0..127
+    const uint32_t c = (uint32_t)((cp ^ ((r >> 1) & 7)) << 4);  // source chunk (swizzle on the source side)
+    // unit row (wr, f, j) -> W row wr*128 + 8 j + f (+ 4 xi)   or   wr*128 + 4 j + f (+ 64 xi)
+    const int x_lo = (r >> 6) * 128 + (r & 15) * (COLS8 ? 8 : 4) + ((r >> 4) & 3);
+    const int y_lo = (r >> 5) * 64 + (r & 31);  // unit row (wc, i) -> A row wc*64 + i (+ yi*32)
+    soff[0][i] = (uint32_t)x_lo * rowbytes + c;
+    soff[2][i] = (uint32_t)(x_lo + (COLS8 ? 4 : 64)) * rowbytes + c;
+    soff[3][i] = (uint32_t)min(y_lo, rmax) * rowbytes + c;
+    soff[1][i] = (uint32_t)min(y_lo + 32, rmax) * rowbytes + c;
+  }
+}
+
+// first column of X fragment (xi, f = 0) of a lane (fr = lane & 15) inside the wave's 128 columns
+template <bool COLS8> __device__ __forceinline__ int col_of(int fr, int xi) { return COLS8 ? fr * 8 + xi * 4 : fr * 4 + xi * 64; }
+
 #define NOVA_BARRIER() asm volatile("s_barrier" ::: "memory")
 #define NOVA_LOOP_BARRIER() do { if (VAR < 12) NOVA_BARRIER(); } while (0)
+
+// The lane-local part of every epilogue: the 4 consecutive output columns a lane holds of one output row.
+// ROT: pair rotation with the row's table entry t = (cos0, sin0, cos1, sin1) (the two pairs of these 4 columns).
+template <typename OT, int EPI, bool ROT>
+__device__ __forceinline__ f4v epi_apply(f4v v, f4v t, float qmul) {
+  if (EPI == E_GELU) {
+    if (sizeof(OT) == 2) {
+      v = gelu_erf_fast4(v);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = gelu_erf(v[q]);
+    }
+  } else if (EPI == E_SILU) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
+  } else if (EPI == E_ROPE) {
+    if (ROT) v = rope_rotate4(v, t);
+    v = v * qmul;  // tile-uniform; x * 1.0f is exact
+  }
+  return v;
+}
+template <typename OT>
+__device__ __forceinline__ void store4(OT* dst, f4v v) {  // 4 consecutive columns of one row
+  if constexpr (sizeof(OT) == 2) {
+    *reinterpret_cast<u2v*>(dst) = u2v{Half16<OT>::pack(v[0], v[1]), Half16<OT>::pack(v[2], v[3])};
+  } else {
+    *reinterpret_cast<f4v*>(dst) = v;
+  }
+}
+template <typename OT>
+__device__ __forceinline__ void store8(OT* dst, f4v lo, f4v hi) {  // 8 consecutive columns of one row
+  if constexpr (sizeof(OT) == 2) {
+    *reinterpret_cast<u4v*>(dst) = u4v{Half16<OT>::pack(lo[0], lo[1]), Half16<OT>::pack(lo[2], lo[3]), Half16<OT>::pack(hi[0], hi[1]), Half16<OT>::pack(hi[2], hi[3])};
+  } else {
+    *reinterpret_cast<f4v*>(dst) = lo;
+    *reinterpret_cast<f4v*>(dst + 4) = hi;
+  }
+}
 
 // VAR selects where the two LDS-DMA instructions of a phase are issued (A/B-tested on the GPU, tools/microbench.py):
 //   0: both between the two k-halves of the MFMA segment   1: one in the load segment, one in the MFMA segment
@@ -94,7 +171,7 @@ template <typename T, int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                          T* __restrict__ C, int M, int N, int K, int ntm, int ntn,
                                                          GemmEpi256 e) {
-  __shared__ __attribute__((aligned(16))) char smem[P_LDS];
+  __shared__ __attribute__((aligned(16))) char smem[P_KLDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
@@ -109,34 +186,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   const int tn = (t % per_group) / gsz;
   const int m0 = tm * 256, n0 = tn * 256;
 
-  // ---- per-lane source pointers of the two LDS-DMA pieces this wave moves for each of the 4 units
-  // unit order u: 0 = A(0), 1 = W(1), 2 = A(1), 3 = W(0)   (the staging order)
-  const int cp = lane & 7;
-  const size_t rowbytes = (size_t)K * sizeof(T);
   // wave-uniform tile bases + per-lane 32-bit byte offsets: the LDS-DMA instructions then take an SGPR base and a
   // 32-bit VGPR offset, and advancing along K is scalar arithmetic (no 64-bit vector add per issue)
+  const size_t rowbytes = (size_t)K * sizeof(T);
   const char* a_base = reinterpret_cast<const char*>(A) + (size_t)m0 * rowbytes;
   const char* w_base = reinterpret_cast<const char*>(W) + (size_t)n0 * rowbytes;
+  constexpr bool COLS8 = EPI != E_ROPE;  // column map of the X fragments (header comment)
   uint32_t soff[4][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (wid * 2 + i) * 8 + (lane >> 3);          // row inside the unit, 0..127
-    const uint32_t c = (uint32_t)((cp ^ ((r >> 1) & 7)) << 4);  // source chunk (swizzle on the source side)
-    const int a_lo = (r >> 6) * 128 + (r & 63);             // + mi*64
-    const int w_lo = (r >> 5) * 64 + (r & 31);              // + ni*32
-    const int rmax = M - 1 - m0;                            // rows past M re-read row M-1 (never stored)
-    soff[0][i] = (uint32_t)min(a_lo, rmax) * (uint32_t)rowbytes + c;
-    soff[2][i] = (uint32_t)min(a_lo + 64, rmax) * (uint32_t)rowbytes + c;
-    soff[3][i] = (uint32_t)w_lo * (uint32_t)rowbytes + c;
-    soff[1][i] = (uint32_t)(w_lo + 32) * (uint32_t)rowbytes + c;
-  }
+  dma_offsets<COLS8>(lane, wid, M - 1 - m0, (uint32_t)rowbytes, soff);
   const int nkt = K / (128 / (int)sizeof(T));
-  // LDS offset of unit u inside a buffer: A(0) A(1) W(0) W(1)
+  // LDS offset of unit u inside a buffer: X(0) X(1) Y(0) Y(1)
   auto unit_off = [](int u) { return (u == 0 ? 0 : u == 2 ? 1 : u == 3 ? 2 : 3) * P_UNIT; };
   auto stage_piece = [&](int u, int kt, int i) {
     if (kt < nkt) {
       char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048 + i * 1024;
-      const char* base = ((u == 0 || u == 2) ? a_base : w_base) + (size_t)kt * 128;
+      const char* base = ((u == 0 || u == 2) ? w_base : a_base) + (size_t)kt * 128;
       __builtin_amdgcn_global_load_lds(base + soff[u][i], NOVA_LDS_PTR(dst), 16, 0, 0);
     }
   };
@@ -147,20 +211,22 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   };
 
   const int fr = lane & 15, fg = lane >> 4;
-  f4v bv[4];  // the accumulators start at the bias (see gemm.hip)
-#pragma unroll
-  for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
+  // the accumulators start at the bias (see gemm.hip): every accumulator of X fragment (xi, f) holds column col_of(fr, xi) + f
+  f4v bcol[2] = {f4v{0.f, 0.f, 0.f, 0.f}, f4v{0.f, 0.f, 0.f, 0.f}};
   if (e.bias) {
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
+    for (int xi = 0; xi < 2; ++xi) bcol[xi] = *reinterpret_cast<const f4v*>(e.bias + n0 + wr * 128 + col_of<COLS8>(fr, xi));
   }
-  f4v acc[4][8];  // [nf][mf]
+  f4v acc[4][8];  // [y fragment][x fragment]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = bv[i];
+    for (int j = 0; j < 8; ++j) {
+      const float b = bcol[j >> 2][j & 3];
+      acc[i][j] = f4v{b, b, b, b};
+    }
 
-  // ---- prologue: q = 0..5 = tile 0 (A0 W1 A1 W0) + tile 1 (A0 W1); wait for tile 0
+  // ---- prologue: q = 0..5 = tile 0 (X0 Y1 X1 Y0) + tile 1 (X0 Y1); wait for tile 0
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
   stage(0, 1); stage(1, 1);
   if (nkt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -168,33 +234,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   NOVA_BARRIER();
   if (wr == 1) NOVA_BARRIER();  // group 1 runs one barrier behind group 0 from here on
 
-  PFrag<T> af[4][2], wf0[2][2], wf1[2][2];
-  auto read_a = [&](const char* buf, int mi) {
+  PFrag<T> xf[4][2], yf0[2][2], yf1[2][2];
+  auto read_x = [&](const char* buf, int xi) {
     if (VAR >= 11 && buf != smem) return;
-    const char* u = buf + mi * P_UNIT;
+    const char* u = buf + xi * P_UNIT;
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) af[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
+      for (int kk = 0; kk < 2; ++kk) xf[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
   };
-  auto read_w = [&](const char* buf, int ni, PFrag<T> (&wf)[2][2]) {
+  auto read_y = [&](const char* buf, int yi, PFrag<T> (&yf)[2][2]) {
     if (VAR >= 11 && buf != smem) return;
-    const char* u = buf + (2 + ni) * P_UNIT;
+    const char* u = buf + (2 + yi) * P_UNIT;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) wf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
+      for (int kk = 0; kk < 2; ++kk) yf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
   };
   // 16 MFMAs of one quadrant; the LDS-DMA prefetch of this phase is issued between the two k halves, where
   // its issue cost hides under the matrix pipe instead of lengthening the other group's critical load segment.
-  auto mma_quadrant = [&](int mi, int ni, PFrag<T> (&wf)[2][2], int su, int skt) {
+  auto mma_quadrant = [&](int xi, int yi, PFrag<T> (&yf)[2][2], int su, int skt) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
+      for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], acc[ni * 2 + nf][mi * 4 + mf]);
+        for (int x = 0; x < 4; ++x) acc[yi * 2 + f][xi * 4 + x] = pmma(yf[f][kk], xf[x][kk], acc[yi * 2 + f][xi * 4 + x]);
       if (kk == 0) {
         if (VAR == 0) stage(su, skt);
         if (VAR == 1) stage_piece(su, skt, 1);
@@ -210,31 +276,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   };
   for (int kt = 0; kt < nkt; ++kt) {
     const char* buf = smem + (kt & 1) * P_BUF;
-    // phase 0: quadrant (0,0); stages q = 4kt+6 = (kt+1, A1)
+    // phase 0: quadrant (0,0); stages q = 4kt+6 = (kt+1, X1)
     lstage_pre(2, kt + 1);
-    read_a(buf, 0);
-    read_w(buf, 0, wf0);
+    read_x(buf, 0);
+    read_y(buf, 0, yf0);
     lstage_post(2, kt + 1);
     NOVA_LOOP_BARRIER();
-    mma_quadrant(0, 0, wf0, 2, kt + 1);
+    mma_quadrant(0, 0, yf0, 2, kt + 1);
     NOVA_LOOP_BARRIER();
-    // phase 1: quadrant (0,1); stages (kt+1, W0)
+    // phase 1: quadrant (0,1); stages (kt+1, Y0)
     lstage_pre(3, kt + 1);
-    read_w(buf, 1, wf1);
+    read_y(buf, 1, yf1);
     lstage_post(3, kt + 1);
     NOVA_LOOP_BARRIER();
-    mma_quadrant(0, 1, wf1, 3, kt + 1);
+    mma_quadrant(0, 1, yf1, 3, kt + 1);
     NOVA_LOOP_BARRIER();
-    // phase 2: quadrant (1,1); stages (kt+2, A0)
+    // phase 2: quadrant (1,1); stages (kt+2, X0)
     lstage_pre(0, kt + 2);
-    read_a(buf, 1);
+    read_x(buf, 1);
     lstage_post(0, kt + 2);
     NOVA_LOOP_BARRIER();
-    mma_quadrant(1, 1, wf1, 0, kt + 2);
+    mma_quadrant(1, 1, yf1, 0, kt + 2);
     NOVA_LOOP_BARRIER();
-    // phase 3: quadrant (1,0) on the W(0) fragments still held from phase 0 (no LDS reads); stages (kt+2, W1).
+    // phase 3: quadrant (1,0) on the Y(0) fragments still held from phase 0 (no LDS reads); stages (kt+2, Y1).
     // Before the first barrier: retire all of tile kt+1 = everything but the youngest unit issued so far
-    // ((kt+2, A0) of phase 2; this phase's unit is issued after the barrier).
+    // ((kt+2, X0) of phase 2; this phase's unit is issued after the barrier).
     // (VAR 1: one more piece of this phase's unit is already issued -> 3; VAR 2/3: the whole unit -> 4)
     lstage_pre(1, kt + 2);
     lstage_post(1, kt + 2);
@@ -247,59 +313,39 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     NOVA_LOOP_BARRIER();
-    mma_quadrant(1, 0, wf0, 1, kt + 2);
+    mma_quadrant(1, 0, yf0, 1, kt + 2);
     NOVA_LOOP_BARRIER();
   }
   if (wr == 0) NOVA_BARRIER();  // re-align the groups
 
-  // ---- epilogue (same lane-local form as gemm.hip): lane holds out[m][n..n+3]
+  // ---- epilogue (lane-local): the lane holds out[rows 4 fg + r of Y fragment y][columns col_of(fr, xi) + {0..3}]
   const bool rot = EPI == E_ROPE && n0 < e.rope_cols;
+  const float qmul = (EPI == E_ROPE && n0 < e.q_cols) ? e.q_scale : 1.0f;
+  const int nw = n0 + wr * 128;
 #pragma unroll
-  for (int mf = 0; mf < 8; ++mf) {
-    const int m_raw = m0 + wr * 128 + mf * 16 + fr;
-    if (__builtin_amdgcn_readfirstlane(m0 + wr * 128 + mf * 16) >= M) continue;  // whole fragment row block past M (wave-uniform)
-    const int m = min(m_raw, M - 1);  // lanes past M recompute row M-1 and store the identical bytes (benign)
-    f4v cs[4];
-    if (rot) {
-      const int s = m / e.L, l = m - s * e.L;
-      const float* ropem = e.rope + ((size_t)(s % e.rope_batch) * e.L + l) * e.hd;
+  for (int y = 0; y < 4; ++y) {
+    const int mb = m0 + wc * 64 + y * 16;
+    if (__builtin_amdgcn_readfirstlane(mb) >= M) continue;  // whole fragment row block past M (wave-uniform)
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) cs[nf] = *reinterpret_cast<const f4v*>(ropem + (n0 + wc * 64 + nf * 16 + fg * 4) % e.hd);
-    }
-    T* dst = C + (size_t)m * N + n0 + wc * 64 + fg * 4;
-    u2v pk[4];
-#pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
-      f4v v = acc[nf][mf];
-      if (EPI == E_GELU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sizeof(T) == 2 ? v[j] : gelu_erf(v[j]);
-        if (sizeof(T) == 2) v = gelu_erf_fast4(v);
-      } else if (EPI == E_SILU) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = silu(v[j]);
-      } else if (EPI == E_ROPE) {
-        if (rot) {
-          v = rope_rotate4(v, cs[nf]);
-        }
-        if (n0 < e.q_cols) v = v * e.q_scale;
+    for (int r = 0; r < 4; ++r) {
+      const int m = min(mb + fg * 4 + r, M - 1);  // lanes past M recompute row M-1 and store the identical bytes (benign)
+      const float* ropem = nullptr;
+      if (rot) {
+        const int s = m / e.L, l = m - s * e.L;
+        ropem = e.rope + ((size_t)(s % e.rope_batch) * e.L + l) * e.hd;
       }
-      if constexpr (sizeof(T) == 2) {
-        pk[nf] = u2v{Half16<T>::pack(v[0], v[1]), Half16<T>::pack(v[2], v[3])};
+      f4v v[2];
+#pragma unroll
+      for (int xi = 0; xi < 2; ++xi) {
+        v[xi] = f4v{acc[y][xi * 4][r], acc[y][xi * 4 + 1][r], acc[y][xi * 4 + 2][r], acc[y][xi * 4 + 3][r]};
+        if (rot) v[xi] = epi_apply<T, EPI, true>(v[xi], *reinterpret_cast<const f4v*>(ropem + (nw + col_of<COLS8>(fr, xi)) % e.hd), qmul);
+        else v[xi] = epi_apply<T, EPI, false>(v[xi], v[xi], qmul);
+      }
+      if constexpr (COLS8) {
+        store8<T>(C + (size_t)m * N + nw + fr * 8, v[0], v[1]);
       } else {
-        *reinterpret_cast<f4v*>(dst + nf * 16) = v;
-      }
-    }
-    if constexpr (sizeof(T) == 2) {
-      // widen the store: v_permlane16_swap exchanges the odd 16-lane rows of fragment a with the even rows of
-      // fragment b, after which a lane holds 8 consecutive bf16 columns -> one 16-byte store per fragment pair
-      // (lanes with fg even: fragment a, fg odd: fragment b; columns 8*(fg>>1) .. +7 of that fragment).
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const auto lo = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
-        u4v o = {lo[0], hi[0], lo[1], hi[1]};
-        *reinterpret_cast<u4v*>(C + (size_t)m * N + n0 + wc * 64 + (2 * pr + (fg & 1)) * 16 + (fg >> 1) * 8) = o;
+        store4<T>(C + (size_t)m * N + nw + col_of<false>(fr, 0), v[0]);
+        store4<T>(C + (size_t)m * N + nw + col_of<false>(fr, 1), v[1]);
       }
     }
   }
@@ -309,11 +355,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 // Persistent form: one workgroup per CU walks its XCD's chunk of the tile list (same tile order as the
 // one-tile-per-workgroup launch above). What it buys on the K = 1024 shapes, where a tile's main loop is only
 // 16 K-tiles long: no workgroup dispatch between tiles, and the first six LDS-DMA units of the NEXT tile are
-// issued in the middle of the epilogue (after the re-align barrier every LDS slot is dead), so their HBM/L2
-// latency hides under the second half of the epilogue's VALU work and stores. vmcnt retires in issue order
-// and counts stores, so the wait at the top of the next tile is vmcnt(4 + stores of the second half).
-// Everything the second half needs from memory (RoPE table rows) is loaded BEFORE those DMAs are issued: a
-// load issued after them could only be consumed once they have all landed.
+// issued at the start of the epilogue (after the re-align barrier every LDS slot is dead), so their HBM/L2
+// latency hides under the epilogue's VALU work and stores. vmcnt retires in issue order and counts stores, so the
+// wait at the top of the next tile is vmcnt(4 + stores of the epilogue).
+// Nothing the compiler has to wait for may be requested while those DMAs are in flight: beside pending LDS-DMA it waits
+// with vmcnt(0) at the first use of an ordinary load (the whole queue, stores included). So the RoPE table rows are
+// loaded and consumed BEFORE the DMAs are issued, and the next tile's bias takes the operands' own route: one 1-KiB
+// LDS-DMA (wave 0) ahead of the prologue units, read from LDS after the wait + barrier at the tile top. (Rounds 1-3
+// loaded the bias into registers in the epilogue: the first MFMA of every tile then sat behind an s_waitcnt vmcnt(0)
+// that drained the just-issued prefetch of K-tile 1 and all of the previous tile's stores.)
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                           typename OutOf<T>::type* __restrict__ C, int M, int N, int K,
@@ -321,9 +371,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   typedef typename OutOf<T>::type OT;
   constexpr bool FP8 = sizeof(T) == 1;
   constexpr bool Q8 = EPI == E_GELU_Q8;
+  constexpr bool COLS8 = EPI != E_ROPE;  // column map of the X fragments (header comment)
   // vector-memory operations a wave issues per tile epilogue behind the next tile's prologue DMAs (exact: the wait at the next
-  // tile top counts them): 16-byte stores of bf16 / f32 results; e4m3 results: 8 stores + 1 atomic max
-  constexpr int STORES_TILE = Q8 ? 9 : (sizeof(OT) == 2 ? 16 : 32);
+  // tile top counts them): one store per output row and 16 bytes = 16 for 16-bit results with the 8-column map, 32 with the
+  // 4-column map and for f32 results; e4m3 results: 16 8-byte stores + 1 atomic max
+  constexpr int STORES_TILE = Q8 ? 17 : (COLS8 && sizeof(OT) == 2) ? 16 : 32;
   __shared__ __attribute__((aligned(16))) char smem[P_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -355,116 +407,112 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   const char *a_base, *w_base;
   uint32_t soff[4][2];
   auto set_tile = [&](int m0, int n0) {
-    const int lane = fresh_lane(), cp = lane & 7;
     a_base = reinterpret_cast<const char*>(A) + (size_t)m0 * rowbytes;
     w_base = reinterpret_cast<const char*>(W) + (size_t)n0 * rowbytes;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = (wid * 2 + i) * 8 + (lane >> 3);
-      const uint32_t c = (uint32_t)((cp ^ ((r >> 1) & 7)) << 4);
-      const int a_lo = (r >> 6) * 128 + (r & 63);
-      const int w_lo = (r >> 5) * 64 + (r & 31);
-      const int rmax = M - 1 - m0;
-      soff[0][i] = (uint32_t)min(a_lo, rmax) * (uint32_t)rowbytes + c;
-      soff[2][i] = (uint32_t)min(a_lo + 64, rmax) * (uint32_t)rowbytes + c;
-      soff[3][i] = (uint32_t)w_lo * (uint32_t)rowbytes + c;
-      soff[1][i] = (uint32_t)(w_lo + 32) * (uint32_t)rowbytes + c;
-    }
+    dma_offsets<COLS8>(fresh_lane(), wid, M - 1 - m0, (uint32_t)rowbytes, soff);
   };
   const int nkt = K / (128 / (int)sizeof(T));
   auto unit_off = [](int u) { return (u == 0 ? 0 : u == 2 ? 1 : u == 3 ? 2 : 3) * P_UNIT; };
   auto stage = [&](int u, int kt) {
     if (kt < nkt) {
       char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048;
-      const char* base = ((u == 0 || u == 2) ? a_base : w_base) + (size_t)kt * 128;
+      const char* base = ((u == 0 || u == 2) ? w_base : a_base) + (size_t)kt * 128;
       __builtin_amdgcn_global_load_lds(base + soff[u][0], NOVA_LDS_PTR(dst), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(base + soff[u][1], NOVA_LDS_PTR(dst + 1024), 16, 0, 0);
     }
   };
-  auto stage_prologue = [&]() {
+  const bool lds_bias = !FP8 && e.bias != nullptr;  // fp8: accumulators start at zero, the scales multiply the raw sums (bias added in the epilogue)
+  // the tile's 256 bias values -> LDS, by wave 0, ahead of (= older than) the prologue units: landed when the wait at the tile top
+  // returns (in-order retirement) and visible to all waves after that wait's barrier
+  auto stage_prologue = [&](int n0) {
+    if (lds_bias && wid == 0)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(e.bias + n0) + lane * 16, NOVA_LDS_PTR(smem + P_BIAS), 16, 0, 0);
     stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
     stage(0, 1); stage(1, 1);
   };
 
   int fr, fg;
-  f4v acc[4][8];  // [nf][mf]
-  PFrag<T> af[4][2], wf0[2][2], wf1[2][2];
-  auto read_a = [&](const char* buf, int mi) {
-    const char* u = buf + mi * P_UNIT;
+  f4v acc[4][8];  // [y fragment][x fragment]
+  PFrag<T> xf[4][2], yf0[2][2], yf1[2][2];
+  auto read_x = [&](const char* buf, int xi) {
+    const char* u = buf + xi * P_UNIT;
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) af[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
+      for (int kk = 0; kk < 2; ++kk) xf[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
   };
-  auto read_w = [&](const char* buf, int ni, PFrag<T> (&wf)[2][2]) {
-    const char* u = buf + (2 + ni) * P_UNIT;
+  auto read_y = [&](const char* buf, int yi, PFrag<T> (&yf)[2][2]) {
+    const char* u = buf + (2 + yi) * P_UNIT;
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) wf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
+      for (int kk = 0; kk < 2; ++kk) yf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
   };
   // The accumulators start at the bias: the first MFMA of every accumulator (k half 0 of the tile's first K-tile) takes
-  // the bias registers as its C operand, so there is neither a zeroing pass nor a bias add in the epilogue.
-  f4v bv[4];
-  auto mma_quadrant = [&](int mi, int ni, PFrag<T> (&wf)[2][2], auto first_ktile) {
+  // the bias of its column, splat over the lane's 4 rows, as its C operand, so there is neither a zeroing pass nor a bias
+  // add in the epilogue.
+  f4v bcol[2];
+  auto mma_quadrant = [&](int xi, int yi, PFrag<T> (&yf)[2][2], auto first_ktile) {
     constexpr bool FIRST = decltype(first_ktile)::value;
+    f4v c0[4];
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) c0[x] = f4v{bcol[xi][x], bcol[xi][x], bcol[xi][x], bcol[xi][x]};
+    }
     __builtin_amdgcn_s_setprio(1);
     if constexpr (FP8) {
       // MX-fp8: ONE v_mfma_scale_f32_16x16x128_f8f6f4 per accumulator and K-tile (twice the bf16 rate). A lane's 32 operand
       // bytes are the two 16-byte chunks (fg, fg + 4) it reads anyway - the same (lane, byte) -> k map on both operands,
       // which is all a contraction needs. Block scales are 1 (e8m0 127); the per-row scales are applied in the epilogue.
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
+      for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-          const i8v wv = __builtin_bit_cast(i8v, __builtin_shufflevector(wf[nf][0].v, wf[nf][1].v, 0, 1, 2, 3, 4, 5, 6, 7));
-          const i8v av = __builtin_bit_cast(i8v, __builtin_shufflevector(af[mf][0].v, af[mf][1].v, 0, 1, 2, 3, 4, 5, 6, 7));
-          acc[ni * 2 + nf][mi * 4 + mf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
-              wv, av, FIRST ? bv[ni * 2 + nf] : acc[ni * 2 + nf][mi * 4 + mf], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        for (int x = 0; x < 4; ++x) {
+          const i8v yv = __builtin_bit_cast(i8v, __builtin_shufflevector(yf[f][0].v, yf[f][1].v, 0, 1, 2, 3, 4, 5, 6, 7));
+          const i8v xv = __builtin_bit_cast(i8v, __builtin_shufflevector(xf[x][0].v, xf[x][1].v, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[yi * 2 + f][xi * 4 + x] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              yv, xv, FIRST ? c0[x] : acc[yi * 2 + f][xi * 4 + x], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int nf = 0; nf < 2; ++nf)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-          for (int mf = 0; mf < 4; ++mf)
-            acc[ni * 2 + nf][mi * 4 + mf] = pmma(wf[nf][kk], af[mf][kk], (FIRST && kk == 0) ? bv[ni * 2 + nf] : acc[ni * 2 + nf][mi * 4 + mf]);
+          for (int x = 0; x < 4; ++x)
+            acc[yi * 2 + f][xi * 4 + x] = pmma(yf[f][kk], xf[x][kk], (FIRST && kk == 0) ? c0[x] : acc[yi * 2 + f][xi * 4 + x]);
     }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto load_bias = [&](int n0) {
+  auto read_bias = [&]() {  // after the tile-top wait + barrier
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
-    if (!FP8 && e.bias) {  // fp8: accumulators start at zero, the scales multiply the raw sums (bias added below)
-#pragma unroll
-      for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wc * 64 + nf * 16 + fg * 4);
-    }
+    for (int xi = 0; xi < 2; ++xi)
+      bcol[xi] = lds_bias ? *reinterpret_cast<const f4v*>(smem + P_BIAS + (wr * 128 + col_of<COLS8>(fr, xi)) * 4) : f4v{0.f, 0.f, 0.f, 0.f};
   };
   // one K-tile: 4 phases (see the header comment)
   auto ktile = [&](int kt, auto first_ktile) {
     const char* buf = smem + (kt & 1) * P_BUF;
-    read_a(buf, 0);
-    read_w(buf, 0, wf0);
+    read_x(buf, 0);
+    read_y(buf, 0, yf0);
     stage(2, kt + 1);
     NOVA_BARRIER();
-    mma_quadrant(0, 0, wf0, first_ktile);
+    mma_quadrant(0, 0, yf0, first_ktile);
     NOVA_BARRIER();
-    read_w(buf, 1, wf1);
+    read_y(buf, 1, yf1);
     stage(3, kt + 1);
     NOVA_BARRIER();
-    mma_quadrant(0, 1, wf1, first_ktile);
+    mma_quadrant(0, 1, yf1, first_ktile);
     NOVA_BARRIER();
-    read_a(buf, 1);
+    read_x(buf, 1);
     stage(0, kt + 2);
     NOVA_BARRIER();
-    mma_quadrant(1, 1, wf1, first_ktile);
+    mma_quadrant(1, 1, yf1, first_ktile);
     NOVA_BARRIER();
     stage(1, kt + 2);
     if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     NOVA_BARRIER();
-    mma_quadrant(1, 0, wf0, first_ktile);
+    mma_quadrant(1, 0, yf0, first_ktile);
     NOVA_BARRIER();
   };
 
@@ -477,19 +525,18 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   auto tile_at = [&](int i) { return cbase + (e.rev ? csize - 1 - i : i); };
   tile_origin(tile_at(it), m0, n0);
   set_tile(m0, n0);
-  { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
-  load_bias(n0);  // older than the DMAs: landed when the wait below returns (in-order retirement)
-  stage_prologue();
+  stage_prologue(n0);
   bool first = true;
   for (;;) {
     { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
-    // K-tile 0 of this tile landed: all but (tile 1: A0, W1) and, after the first tile, everything the previous
-    // epilogue issued after the prologue DMAs (at least its STORES_TILE stores)
+    // K-tile 0 of this tile (and its bias) landed: all but (tile 1: X0, Y1) and, after the first tile, everything the previous
+    // epilogue issued after the prologue DMAs (its STORES_TILE stores)
     if (nkt == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (first) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + STORES_TILE) : "memory");
     NOVA_BARRIER();
     if (wr == 1) NOVA_BARRIER();  // group 1 runs one barrier behind group 0 inside the K loop
+    read_bias();
     ktile(0, std::true_type{});
     for (int kt = 1; kt < nkt; ++kt) ktile(kt, std::false_type{});
     if (wr == 0) NOVA_BARRIER();  // re-align the groups: every LDS slot is dead from here on
@@ -502,169 +549,114 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
     { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
     const bool rot = EPI == E_ROPE && cn0 < e.rope_cols;
     const float qmul = (EPI == E_ROPE && cn0 < e.q_cols) ? e.q_scale : 1.0f;  // tile-uniform; x * 1.0f is exact
-    // four groups of 2 fragment row blocks. The next tile's prologue DMAs go out FIRST, ahead of this tile's stores in
-    // the memory pipeline (issued behind them they queue for ~7k cycles). What the epilogue needs from memory before
-    // it can start (the RoPE rows of groups 0-1) is therefore consumed before the DMAs are issued; the RoPE rows
-    // of groups 2-3 are requested after them and arrive behind them (in-order retirement), by which time they are done.
+    const int nw = cn0 + wr * 128;  // the wave's first column; the lane's 4 columns of half xi start at nw + col_of(fr, xi)
     // fp8: out = acc * sa[row] * sw[col] + bias[col]; the three vectors are requested first and consumed before the DMAs
-    f4v swv[4], bfv[4];
-    float sav[8];
     if constexpr (FP8) {
+      f4v swv[2], bfv[2], sav[4];
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) {
-        swv[nf] = *reinterpret_cast<const f4v*>(e.sw + cn0 + wc * 64 + nf * 16 + fg * 4);
-        bfv[nf] = e.bias ? *reinterpret_cast<const f4v*>(e.bias + cn0 + wc * 64 + nf * 16 + fg * 4) : f4v{0.f, 0.f, 0.f, 0.f};
+      for (int xi = 0; xi < 2; ++xi) {
+        swv[xi] = *reinterpret_cast<const f4v*>(e.sw + nw + col_of<COLS8>(fr, xi));
+        bfv[xi] = e.bias ? *reinterpret_cast<const f4v*>(e.bias + nw + col_of<COLS8>(fr, xi)) : f4v{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int mf = 0; mf < 8; ++mf) sav[mf] = e.sa[e.sa_scalar ? 0 : min(cm0 + wr * 128 + mf * 16 + fr, M - 1)];
-      asm volatile("" ::"v"(sav[7]));  // youngest of them: the compiler's wait sits here (loads retire in order)
-      // dequantise in place, ahead of everything else: the three scale / bias vectors (40 registers) are dead before the
-      // epilogue proper starts to load its RoPE rows (kept live through it they cost the RoPE variant 97 spilled VGPRs)
+      for (int y = 0; y < 4; ++y)
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
+        for (int r = 0; r < 4; ++r) sav[y][r] = e.sa[e.sa_scalar ? 0 : min(cm0 + wc * 64 + y * 16 + fg * 4 + r, M - 1)];
+      asm volatile("" ::"v"(sav[3][3]));  // youngest of them: the compiler's wait sits here (loads retire in order)
+      // dequantise in place, ahead of everything else: the scale / bias vectors are dead before the epilogue proper starts
 #pragma unroll
-        for (int mf = 0; mf < 8; ++mf) acc[nf][mf] = (acc[nf][mf] * sav[mf]) * swv[nf] + bfv[nf];
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc[y][x] = (acc[y][x] * sav[y]) * swv[x >> 2][x & 3] + bfv[x >> 2][x & 3];
     }
-#ifdef NOVA_ROPE_HALF_TABLE  // timing-only experiment (tools/ab_lib.py, never shipped): the cos / sin table read as f16 - half the bytes, half the registers
-    typedef u2v CsT;
-#else
-    typedef f4v CsT;
-#endif
-    CsT cs[4][2][4];  // [group][row block][nf]
-    int coff[4];      // column of this lane's 4 floats inside a table row (head-relative), per nf
-    if (rot) {
+    // RoPE table rows of the lane's 16 output rows: (cos0, sin0, cos1, sin1) of the pairs in its 4 columns. When the head
+    // width divides 64 both column halves of the wave see the same table columns (the common case: head_dim 64); otherwise
+    // (head_dim 96) the table rows of half 1 are loaded after half 0 is done.
+    f4v cs[4][4];  // [y fragment][r]
+    const bool same_cols = 64 % e.hd == 0;
+    auto load_cs = [&](int xi) {
+      const int tcol = (nw + col_of<COLS8>(fr, xi)) % e.hd;
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) coff[nf] = (cn0 + wc * 64 + nf * 16 + fg * 4) % e.hd;
-    }
-    const int nxt = it + nslot;
-    const bool more = nxt < csize;
-    auto load_cs = [&](int g) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        // (sequence, position) of the row block's first row on wave-uniform values, the lane's row by increment
-        const int mb = min(__builtin_amdgcn_readfirstlane(cm0 + wr * 128 + (2 * g + j) * 16), M - 1);
+      for (int y = 0; y < 4; ++y) {
+        // (sequence, position) of the fragment's first row on wave-uniform values, the lane's rows by increment
+        const int mb = min(__builtin_amdgcn_readfirstlane(cm0 + wc * 64 + y * 16), M - 1);
         const int s0 = mb / e.L, l0 = mb - s0 * e.L;
         const int b0 = s0 % e.rope_batch, b1 = b0 + 1 == e.rope_batch ? 0 : b0 + 1;
-        int l = l0 + min(fr, M - 1 - mb);  // rows past M reuse row M-1 (never stored differently)
-        int sb = b0;
-        if (l >= e.L) { l -= e.L; sb = b1; }  // a 16-row block crosses at most one sequence boundary (L >= 16)
-#ifdef NOVA_ROPE_HALF_TABLE
-        const uint16_t* roph = reinterpret_cast<const uint16_t*>(e.rope) + ((size_t)sb * e.L + l) * e.hd;
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) cs[g][j][nf] = *reinterpret_cast<const u2v*>(roph + coff[nf]);
-#else
-        const float* ropem = e.rope + ((size_t)sb * e.L + l) * e.hd;
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) cs[g][j][nf] = *reinterpret_cast<const f4v*>(ropem + coff[nf]);
-#endif
+        for (int r = 0; r < 4; ++r) {
+          int l = l0 + min(fg * 4 + r, M - 1 - mb);  // rows past M reuse row M-1 (never stored differently)
+          int sb = b0;
+          if (l >= e.L) { l -= e.L; sb = b1; }  // a 16-row block crosses at most one sequence boundary (L >= 16)
+          cs[y][r] = *reinterpret_cast<const f4v*>(e.rope + ((size_t)sb * e.L + l) * e.hd + tcol);
+        }
       }
     };
     float q8_inv = 1.0f, q8_max = 0.f;
     if constexpr (Q8) q8_inv = 1.0f / *e.q8_scale;
-    auto finish_group = [&](int g, auto rotated) {
+    // rows past M were staged as copies of row M-1, so their lanes hold row M-1's results and store the identical
+    // bytes there again: no branch, and every tile issues the same number of stores (the vmcnt count above)
+    auto row_of = [&](int y, int r) { return min(cm0 + wc * 64 + y * 16 + fg * 4 + r, M - 1); };
+    auto value4 = [&](int y, int r, int xi) { return f4v{acc[y][xi * 4][r], acc[y][xi * 4 + 1][r], acc[y][xi * 4 + 2][r], acc[y][xi * 4 + 3][r]}; };
+    auto finish_half = [&](int xi, auto rotated) {  // COLS4: the lane's 4 columns of half xi, all 16 rows
       constexpr bool ROT = decltype(rotated)::value;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int mf = 2 * g + j;
-        // rows past M were staged as copies of row M-1, so their lanes hold row M-1's results and store the identical
-        // bytes there again: no branch, and every tile issues the same number of stores (the vmcnt count above)
-        const int m = min(cm0 + wr * 128 + mf * 16 + fr, M - 1);
-        if constexpr (Q8) {
-          uint32_t d[4];  // this lane's 4 columns of every 16-column fragment as 4 e4m3 bytes
+      for (int y = 0; y < 4; ++y)
 #pragma unroll
-          for (int nf = 0; nf < 4; ++nf) {
-            f4v v = gelu_erf_fast4(acc[nf][mf]);
+        for (int r = 0; r < 4; ++r)
+          store4<OT>(C + (size_t)row_of(y, r) * N + nw + col_of<false>(fr, xi), epi_apply<OT, EPI, ROT>(value4(y, r, xi), cs[y][r], qmul));
+    };
+    auto finish_rows = [&]() {  // COLS8: the lane's 8 consecutive columns, all 16 rows
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f4v lo = value4(y, r, 0), hi = value4(y, r, 1);
+          if constexpr (Q8) {
+            lo = gelu_erf_fast4(lo);
+            hi = gelu_erf_fast4(hi);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              q8_max = fmaxf(q8_max, fabsf(v[q]));
-              v[q] = __builtin_amdgcn_fmed3f(v[q] * q8_inv, -448.0f, 448.0f);
+              q8_max = fmaxf(q8_max, fmaxf(fabsf(lo[q]), fabsf(hi[q])));
+              lo[q] = __builtin_amdgcn_fmed3f(lo[q] * q8_inv, -448.0f, 448.0f);
+              hi[q] = __builtin_amdgcn_fmed3f(hi[q] * q8_inv, -448.0f, 448.0f);
             }
-            int w = 0;
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w, false);
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w, true);
-            d[nf] = (uint32_t)w;
-          }
-          // 4 x 4 transpose of dwords between the wave's four 16-lane rows (fg) and the four fragments (nf): afterwards the
-          // lane in row fg holds fragment nf = fg's columns 0..15 of its matrix row = 16 contiguous bytes, one 16-byte store
-          const auto s01 = __builtin_amdgcn_permlane16_swap(d[0], d[1], false, false);
-          const auto s23 = __builtin_amdgcn_permlane16_swap(d[2], d[3], false, false);
-          const auto sac = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
-          const auto sbd = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
-          u4v o = {sac[0], sbd[0], sac[1], sbd[1]};
-          *reinterpret_cast<u4v*>(reinterpret_cast<uint8_t*>(C) + (size_t)m * N + cn0 + wc * 64 + fg * 16) = o;
-          continue;
-        }
-        u2v pk[4];
-#pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-          f4v v = acc[nf][mf];
-          if (EPI == E_GELU) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = sizeof(OT) == 2 ? v[q] : gelu_erf(v[q]);
-            if (sizeof(OT) == 2) v = gelu_erf_fast4(v);
-          } else if (EPI == E_SILU) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = silu(v[q]);
-          } else if (EPI == E_ROPE) {
-            if constexpr (ROT) {
-#ifdef NOVA_ROPE_HALF_TABLE
-              const f2v ta = Half16<f16_t>::unpack(cs[g][j][nf][0]), tb = Half16<f16_t>::unpack(cs[g][j][nf][1]);
-              v = rope_rotate4(v, f4v{ta[0], ta[1], tb[0], tb[1]});
-#else
-              v = rope_rotate4(v, cs[g][j][nf]);
-#endif
-            }
-            v = v * qmul;
-          }
-          if constexpr (sizeof(OT) == 2) {
-            pk[nf] = u2v{Half16<OT>::pack(v[0], v[1]), Half16<OT>::pack(v[2], v[3])};
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[0], lo[1], w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(lo[2], lo[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(hi[0], hi[1], w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(hi[2], hi[3], w1, true);
+            // 8 columns = 8 bytes per lane; the 16 lanes of a row group write 128 contiguous bytes
+            *reinterpret_cast<u2v*>(reinterpret_cast<uint8_t*>(C) + (size_t)row_of(y, r) * N + nw + fr * 8) = u2v{(uint32_t)w0, (uint32_t)w1};
           } else {
-            *reinterpret_cast<f4v*>(C + (size_t)m * N + cn0 + wc * 64 + fg * 4 + nf * 16) = v;
+            store8<OT>(C + (size_t)row_of(y, r) * N + nw + fr * 8, epi_apply<OT, EPI, false>(lo, lo, qmul), epi_apply<OT, EPI, false>(hi, hi, qmul));
           }
         }
-        if constexpr (sizeof(OT) == 2) {  // 16-byte stores through v_permlane16_swap, as in the kernel above
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const auto lo = __builtin_amdgcn_permlane16_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
-            const auto hi = __builtin_amdgcn_permlane16_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
-            u4v o = {lo[0], hi[0], lo[1], hi[1]};
-            *reinterpret_cast<u4v*>(C + (size_t)m * N + cn0 + wc * 64 + (2 * pr + (fg & 1)) * 16 + (fg >> 1) * 8) = o;
-          }
-        }
-      }
     };
+    // the next tile's origin, then its prologue (bias + six units) ahead of this tile's stores in the memory pipeline
+    // (issued behind them the DMAs queue for thousands of cycles)
+    const int nxt = it + nslot;
+    const bool more = nxt < csize;
+    if (more) tile_origin(tile_at(nxt), m0, n0);
     auto next_prologue = [&]() {
       if (more) {
         set_tile(m0, n0);
-        stage_prologue();
+        stage_prologue(n0);
       }
     };
-    // the next tile's origin and its bias first: the bias loads are older than everything else this epilogue issues
-    // and have landed when the wait at the next tile top returns
-    if (more) {
-      tile_origin(tile_at(nxt), m0, n0);
-      if (!rot) load_bias(n0);  // (rotating tiles: after groups 0-1, when 64 accumulator registers are free)
-    }
-    // the rotation is tile-uniform (decided per 256-column tile): two straight-line epilogues behind one scalar branch
-    if (rot) {
-      load_cs(0);
-      load_cs(1);
-      asm volatile("" ::"v"(cs[1][1][3]));  // same for the table rows of groups 0-1 (loads retire in order)
+    if constexpr (COLS8) {
       next_prologue();
-      finish_group(0, std::true_type{});
-      finish_group(1, std::true_type{});
-      __builtin_amdgcn_sched_barrier(0);  // keep the later groups' table loads below groups 0-1 (register budget)
-      if (more) load_bias(n0);
-      load_cs(2);
-      load_cs(3);
-      finish_group(2, std::true_type{});
-      finish_group(3, std::true_type{});
+      finish_rows();
+    } else if (rot) {  // the rotation is tile-uniform (decided per 256-column tile): two straight-line epilogues behind one scalar branch
+      load_cs(0);
+      asm volatile("" ::"v"(cs[3][3]));  // the compiler's wait for the table rows sits here, ahead of the DMAs (loads retire in order)
+      next_prologue();
+      finish_half(0, std::true_type{});
+      if (!same_cols) load_cs(1);  // (waits for everything in flight: head widths that do not divide 64 only)
+      finish_half(1, std::true_type{});
     } else {
       next_prologue();
-      finish_group(0, std::false_type{});
-      finish_group(1, std::false_type{});
-      finish_group(2, std::false_type{});
-      finish_group(3, std::false_type{});
+      finish_half(0, std::false_type{});
+      finish_half(1, std::false_type{});
     }
     if constexpr (Q8) {  // one atomic max per wave and tile (values are >= 0: float order == unsigned order of the bits)
       q8_max = wave_max(q8_max);

@@ -165,6 +165,11 @@ int row_norm_bwd(const RowNormBwdArgs& a, int parts, int dtype, hipStream_t st) 
   if (a.mod && (a.mod_ld % vec || (a.scale_off >= 0 && (a.scale_off % vec || a.shift_off % vec || a.shift_off < 0)) ||
                 (a.gate_off >= 0 && a.gate_off % vec)))
     return set_error(NOVA_ERR_SHAPE, "row_norm_bwd: modulation offsets must be multiples of %d", vec);
+  if (a.mod) {  // every term's D columns inside a modulation row, and somewhere to put their gradients
+    for (int off : {a.scale_off, a.shift_off, a.gate_off})
+      if (off >= 0 && (long)off + a.D > a.mod_ld) return set_error(NOVA_ERR_SHAPE, "row_norm_bwd: modulation offset %d + D %d exceeds the row stride %ld", off, a.D, (long)a.mod_ld);
+    if (!a.dmod) return set_error(NOVA_ERR_ARG, "row_norm_bwd: modulation terms given without a gradient buffer (dmod)");
+  }
   if ((a.gamma == nullptr) != (a.beta == nullptr)) return set_error(NOVA_ERR_ARG, "row_norm_bwd: gamma/beta must come together");
   if ((a.dgamma_part == nullptr) != (a.dbeta_part == nullptr) || (a.gamma && !a.dgamma_part))
     return set_error(NOVA_ERR_ARG, "row_norm_bwd: an affine norm needs both partial-sum buffers");

@@ -41,20 +41,28 @@ class GradientReducer(object):
         to the exchange (the payload must have one shape on every rank) and keeps `grad = None` afterwards unless some rank
         did produce one - so parameters off the current path (frame mixer, frame patch-embed at T = 1) get no weight decay or
         moment updates, exactly as in a single-process run and in the reference."""
-        if not self.active:
+        if not self.active or not self.params:
             return
+        # every bucket's all_reduce is queued first; the has-gradient flags of ALL parameters travel as one extra small tensor and are
+        # read back once, after the last collective is queued (a host read per bucket would serialise bucket k + 1's concat and
+        # collective behind bucket k's completion)
+        dev = self.params[0].device
+        flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params], dtype=torch.float32, device=dev)
+        flats = []
         for bucket in self.buckets:
-            has = torch.tensor([0.0 if p.grad is None else 1.0 for p in bucket], dtype=torch.float32, device=bucket[0].device)
-            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket] + [has.to(bucket[0].dtype)])
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            anyone = flat[-len(bucket):].float() > 0
-            flat = flat[:-len(bucket)].div_(self.world)
+            flats.append(flat)
+        dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group)
+        used_by = dict(zip((id(p) for p in self.params), (flags > 0).tolist()))
+        for bucket, flat in zip(self.buckets, flats):
+            flat.div_(self.world)
             off = 0
-            for p, used in zip(bucket, anyone.tolist()):
+            for p in bucket:
                 g = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
                 if p.grad is None:
-                    if used:
+                    if used_by[id(p)]:
                         p.grad = g.clone()
                 else:
                     p.grad.copy_(g)

@@ -143,7 +143,8 @@ class Block(nn.Module):
             return _backend.engine().block_stack_forward([self], x, pe_func)
         if _backend.train_norm_supported(x, gamma=self.norm1.weight, res=x):
             # training on the GPU: branch + LayerNorm + residual, the norm and the add as ONE row kernel forward and ONE backward
-            # (csrc/rowops.hip, csrc/rownorm_bwd.hip) - the same arithmetic as the two lines below
+            # (csrc/rowops.hip, csrc/rownorm_bwd.hip) - the same arithmetic as the two lines below. The check here is on x alone
+            # (device, width); whether the kernel applies is decided per branch on the tensors it would actually get
             return self._post_norm_fused(self._post_norm_fused(x, "attn"), "mlp")
         x = x + self.forward_ckpt(x, "attn")
         return x + self.forward_ckpt(x, "mlp")
@@ -153,7 +154,12 @@ class Block(nn.Module):
         fused = _backend.autograd().fused_norm
 
         def branch(t):
-            return fused(inner(t), gamma=norm.weight, beta=norm.bias, res=t, eps=norm.eps)
+            y = inner(t)
+            # under torch.autocast (the reference trainer: train_newloss.py:1049, f32 parameters) the branch output is fp16 / bf16
+            # while the residual stream stays f32: the row kernel takes ONE storage type, so such a pair goes the torch way
+            if _backend.train_norm_supported(y, gamma=norm.weight, res=t):
+                return fused(y, gamma=norm.weight, beta=norm.bias, res=t, eps=norm.eps)
+            return norm(y) + t
 
         recompute = getattr(self, name + "_checkpointing", False) and x.requires_grad
         return checkpoint(branch, x, use_reentrant=False) if recompute else branch(x)

@@ -116,6 +116,9 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+ABI_VERSION = 400  # == NOVA_HIP_VERSION of include/nova_hip.h (tests/test_abi.py compares the two)
+
+
 def load(check_device=True):
     """Load (once) and return the ctypes handle. Raises NovaHipError if it cannot."""
     global _lib, _device_ok
@@ -131,6 +134,10 @@ def load(check_device=True):
                 lib = ctypes.CDLL(_LIB_PATH)
             except OSError as e:  # pragma: no cover
                 raise NovaHipError(f"cannot load {_LIB_PATH}: {e}") from e
+            lib.nova_version.restype = c_int
+            if lib.nova_version() != ABI_VERSION:  # a stale build would take e.g. `stream` where `key_limit` now sits
+                raise NovaHipError(f"{_LIB_PATH} is C ABI version {lib.nova_version()}, this package binds version {ABI_VERSION} "
+                                   "(include/nova_hip.h NOVA_HIP_VERSION): rebuild it with `make -C nova_pointcloud_amd/csrc`")
             for name, argtypes in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.argtypes, fn.restype = argtypes, c_int

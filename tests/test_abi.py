@@ -37,6 +37,7 @@ def test_ctypes_table_matches_header(built_lib):
     assert table == declared_symbols(), sorted(table ^ declared_symbols())
     lib = built_lib.load(check_device=False)   # binds every symbol; no compute without a GPU
     assert lib.nova_version() == int(re.search(r"#define NOVA_HIP_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.nova_version() == built_lib.ABI_VERSION  # what hip.load() insists on: a stale library fails loudly instead of mis-binding
 
 
 def test_every_entry_point_cites_the_reference():

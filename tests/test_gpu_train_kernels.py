@@ -335,6 +335,44 @@ def test_training_modules_take_the_fused_norm_and_match_the_torch_definition(hip
             assert _rel(grads[n], p.grad) < 1e-3, n
 
 
+@pytest.mark.parametrize("amp", [torch.float16, torch.bfloat16])
+def test_block_under_autocast_with_f32_parameters_matches_the_torch_composition(hip, amp):
+    """The reference trainer runs the model under torch.cuda.amp.autocast() with f32 parameters (train_newloss.py:1049): inside a
+    Block the branch output (a Linear under autocast) is 16-bit while the residual stream (LayerNorm outputs, f32 input) stays f32.
+    The fused norm + residual kernel takes ONE storage type, so that pair must go the torch way - not read the f32 residual as
+    halves (round-3 defect: the support check compared x with itself). Same loss and gradients as with the fused norms disabled,
+    and the autograd function itself refuses mismatched operand types."""
+    from diffnext.models.vision_transformer import Block
+    from nova_pointcloud_amd import autograd as A
+
+    torch.manual_seed(13)
+    mod = Block(256, 4).cuda().float()
+    x = (torch.randn(2, 70, 256) * 0.7).cuda().requires_grad_(True)
+
+    def step():
+        mod.zero_grad()
+        x.grad = None
+        with torch.autocast("cuda", dtype=amp):
+            out = mod(x)
+        out.float().square().mean().backward()
+        return out.detach().float(), x.grad.clone(), {n: p.grad.clone() for n, p in mod.named_parameters()}
+
+    out, gx, gp = step()
+    A._NORM_ENABLED = False
+    try:
+        ref, rgx, rgp = step()
+    finally:
+        A._NORM_ENABLED = True
+    assert out.dtype == ref.dtype and torch.isfinite(out).all()
+    assert _rel(out, ref) < 1e-5 and _rel(gx, rgx) < 1e-4
+    for n in gp:
+        assert _rel(gp[n], rgp[n]) < 1e-4, n
+    y16, res32 = torch.randn(8, 256, device="cuda", dtype=amp), torch.randn(8, 256, device="cuda")
+    assert not A.fused_norm_supported(y16, gamma=mod.norm1.weight, res=res32)
+    with pytest.raises(TypeError):
+        A.fused_norm(y16, gamma=mod.norm1.weight, beta=mod.norm1.bias, res=res32)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Pointwise activations of the MLPs, forward and backward (csrc/rownorm_bwd.hip act_kernel; reference vision_transformer.py:35,38
 # nn.GELU(), diffusion_mlp.py:33,36 and normalization.py:32,35 nn.SiLU())

@@ -153,6 +153,35 @@ def test_ddpm_scheduler_steps():
     assert torch.isfinite(x).all()
 
 
+def test_ddpm_scheduler_and_engine_plan_hit_the_hand_derived_known_answer():
+    """The literals of tests/test_oracle.py::test_ddpm_known_answer_derived_by_hand_from_the_source_text (2 steps over 4 training
+    timesteps, linear betas 0.1 .. 0.4, worked out by hand from scheduling_ddpm.py:143-146,196-199,268-305,319-325) against the
+    drop-in's DDPMScheduler class and the per-step plan the HIP engine hands to nova_sampler_step."""
+    from test_oracle import DDPM_KNOWN_ANSWER as want
+
+    kw = dict(num_train_timesteps=4, beta_start=0.1, beta_end=0.4)
+    # the drop-in's scheduler class: one step from known x, eps with the noise replaced by a constant field
+    from nova_pointcloud_amd.engine import sampler_plan
+
+    sch = DDPMScheduler(clip_sample=False, **kw)
+    sch.set_timesteps(2)
+    assert [int(t) for t in sch.timesteps] == [2, 0]
+    x, eps = torch.full((1, 1, 2, 2), 0.5), torch.full((1, 1, 2, 2), -0.25)
+    kx, kv, c0, cx, sg, _ = want[2]
+    mean2 = c0 * (kx * 0.5 + kv * -0.25) + cx * 0.5  # = 0.876901... by the literals above
+    draws = torch.Generator().manual_seed(3)
+    noise = torch.randn(1, 1, 2, 2, generator=torch.Generator().manual_seed(3))
+    got = sch.step(eps, sch.timesteps[0], x.clone(), generator=draws).prev_sample
+    assert (got - (mean2 + sg * noise)).abs().max() <= 2e-6
+    last = sch.step(eps, sch.timesteps[1], x.clone(), generator=draws).prev_sample  # t = 0: the predicted x0, no noise
+    assert (last - (want[0][0] * 0.5 + want[0][1] * -0.25)).abs().max() <= 2e-6
+    ts, coefs, ancestral = sampler_plan(sch, 2)  # what nova_sampler_step receives per step: (kx, kv, clip, c0, cx, sigma)
+    assert ancestral and [int(v) for v in ts] == [2, 0]
+    for (kx_, kv_, clip, c0_, cx_, sg_), t in zip(coefs, (2, 0)):
+        w = want[t]
+        assert clip == 0.0 and max(abs(kx_ - w[0]), abs(kv_ - w[1]), abs(c0_ - w[2]), abs(cx_ - w[3]), abs(sg_ - w[4])) <= 2e-6
+
+
 def test_save_and_load_roundtrip(gold, tmp_path):
     model = build_from_golden(gold)
     pipe = NOVAPipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler(shift=2.0))

@@ -99,6 +99,34 @@ def test_ddpm_plan_basics():
     assert abs(cx) < 1e-6 and abs(c0 - 1.0) < 1e-6  # last step returns the predicted x0
 
 
+# t: (kx, kv) of epsilon-prediction, c0, cx, sigma(fixed_small), sigma(fixed_large) - see the test below
+DDPM_KNOWN_ANSWER = {
+    2: (1.4085904245475278, -0.9920317455237933, 0.8415738934319075, 0.15087328172475567, 0.29784169859063525, 0.66332495807108),
+    0: (1.0540925533894598, -0.3333333333333333, 1.0, 0.0, 0.0, 0.0),
+}
+
+
+def test_ddpm_known_answer_derived_by_hand_from_the_source_text():
+    """a20 (parity unpinned by execution: the reference's DDPMScheduler imports diffusers): the coefficients of a 2-step chain over
+    4 training timesteps with linear betas, worked out BY HAND from the formulas in scheduling_ddpm.py:143-146 (betas = linspace
+    (0.1, 0.4, 4) -> alphas_cumprod = 0.9, 0.72, 0.504, 0.3024), :196-199 (leading spacing: timesteps 2, 0), :319-325 (previous
+    timestep = t - 4 // 2), :268-285 (alpha_t / alpha_prev, predicted x0), :289-294 (mu coefficients), :211-222,297-305
+    (fixed_small: variance = (1 - a_prev) / (1 - a_t) * beta_t, its square root scales the noise, none at t = 0; fixed_large: beta_t).
+    The literals below are those numbers (DDPM_KNOWN_ANSWER; tests/test_mirror_cpu.py holds the drop-in's scheduler class and the HIP
+    engine's per-step plan to the same literals)."""
+    want = DDPM_KNOWN_ANSWER
+    kw = dict(num_train_timesteps=4, beta_start=0.1, beta_end=0.4)
+    for vt, col in (("fixed_small", 4), ("fixed_large", 5)):
+        plan = O.ddpm_plan(2, variance_type=vt, **kw)
+        assert [p[0] for p in plan] == [2, 0]
+        for t, kx, kv, c0, cx, sigma in plan:
+            w = want[t]
+            for got, exp in ((kx, w[0]), (kv, w[1]), (c0, w[2]), (cx, w[3]), (sigma, w[col])):
+                assert abs(got - exp) <= 2e-6, (vt, t, got, exp)
+    vp = O.ddpm_plan(2, prediction_type="v_prediction", **kw)[0]  # :277-278: x0 = sqrt(a_t) x - sqrt(1 - a_t) v
+    assert abs(vp[1] - 0.7099295739719539) <= 2e-6 and abs(vp[2] + 0.7042726744663603) <= 2e-6
+
+
 # ---------------------------------------------------------------------------------------------
 # multi-frame generation (KV-cached conditioning encoder, frame mixer, motion tokens) and 3-pass guidance:
 # the oracle against runs of the reference's own generate_video (tests/golden/make_golden_video.py)
