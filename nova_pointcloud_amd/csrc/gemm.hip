@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 // gemm256.hip: 256x256 ping-pong kernel for large M
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
-                   hipStream_t st, bool one_tile_per_workgroup = false);
+                   hipStream_t st, int form = 0);  // 0 shipped choice, 1 one tile per workgroup, 2 persistent prologue form
 int gemm256_cu_count();  // CUs of the device = the persistent kernel's grid
 
 // 0 = auto, 128 / 256 = force that tile structure (tests compare the two structures bit for bit). Thread-local like
@@ -233,8 +233,8 @@ int gemm_force_tile(int tile) {
   } else {
     skinny_force_row_blocks(0);
   }
-  if (tile != 0 && tile != 16 && tile != 128 && tile != 256 && tile != 257) return -1;
-  g_force_tile = tile;  // 257: the 256 tile in its one-tile-per-workgroup form (the fallback of the persistent kernel);
+  if (tile != 0 && tile != 16 && tile != 128 && tile != 256 && tile != 257 && tile != 258) return -1;
+  g_force_tile = tile;  // 257: the 256 tile in its one-tile-per-workgroup form; 258: its persistent prologue form (256: the shipped choice);
   return 0;             // 16: the small-M kernel of skinny.hip wherever its shapes allow (an error elsewhere)
 }
 
@@ -264,7 +264,7 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
   const long tiles256 = (long)((M + 255) / 256) * (N / 256);
   if (can256 && (g_force_tile >= 256 || (g_force_tile == 0 && M >= 4096 && tiles256 >= min_tiles256())))
     return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols, e.q_scale, e.q_cols,
-                          dtype_of<T>(), st, g_force_tile == 257);
+                          dtype_of<T>(), st, g_force_tile == 257 ? 1 : g_force_tile == 258 ? 2 : 0);
   const int ntm = (M + BM - 1) / BM, ntn = N / BN;
   dim3 grid(ntm * ntn), block(256);
   ProfScope prof(PROF_GEMM_SMALL, 2.0 * M * N * K, st);

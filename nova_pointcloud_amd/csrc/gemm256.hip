@@ -351,6 +351,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   }
 }
 
+#ifdef NOVA_STAMPS
+// Diagnostic build only (tools/gemm_stamps.py; never in the shipped library): workgroup 0 records the shader clock at eight points
+// of every tile, for one wave of each group (waves 0 and 4), into LDS (an LDS store: nothing is added to the vector-memory queue
+// whose counts the kernel's waits rely on) and copies the record to g_gemm_stamps when it exits.
+constexpr int STAMP_TILES = 64, STAMP_PTS = 8;
+__device__ uint32_t g_gemm_stamps[2 * STAMP_TILES * STAMP_PTS];
+#define NOVA_STAMP(k)                                                                                                            \
+  do {                                                                                                                           \
+    if (blockIdx.x == 0 && (wid & 3) == 0 && lane == 0 && stamp_tile < STAMP_TILES)                                               \
+      reinterpret_cast<uint32_t*>(smem + P_LDS)[((wid >> 2) * STAMP_TILES + stamp_tile) * STAMP_PTS + (k)] = (uint32_t)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+constexpr int P_STAMPS = 2 * STAMP_TILES * STAMP_PTS * 4;
+#else
+#define NOVA_STAMP(k) do {} while (0)
+constexpr int P_STAMPS = 0;
+#endif
+
 // ------------------------------------------------------------------------------------------
 // Persistent form: one workgroup per CU walks its XCD's chunk of the tile list (same tile order as the
 // one-tile-per-workgroup launch above). What it buys on the K = 1024 shapes, where a tile's main loop is only
@@ -376,10 +393,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   // tile top counts them): one store per output row and 16 bytes = 16 for 16-bit results with the 8-column map, 32 with the
   // 4-column map and for f32 results; e4m3 results: 16 8-byte stores + 1 atomic max
   constexpr int STORES_TILE = Q8 ? 17 : (COLS8 && sizeof(OT) == 2) ? 16 : 32;
-  __shared__ __attribute__((aligned(16))) char smem[P_LDS];
+  __shared__ __attribute__((aligned(16))) char smem[P_LDS + P_STAMPS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
+  [[maybe_unused]] int stamp_tile = 0;
 
   // this workgroup's share of the tile list: XCD x = blockIdx % 8 owns one contiguous chunk (xcd_remap's
   // split), its gridDim/8 workgroups take that chunk's tiles round-robin
@@ -529,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
   bool first = true;
   for (;;) {
     { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
+    NOVA_STAMP(0);
     // K-tile 0 of this tile (and its bias) landed: all but (tile 1: X0, Y1) and, after the first tile, everything the previous
     // epilogue issued after the prologue DMAs (its STORES_TILE stores)
     if (nkt == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -536,10 +555,16 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + STORES_TILE) : "memory");
     NOVA_BARRIER();
     if (wr == 1) NOVA_BARRIER();  // group 1 runs one barrier behind group 0 inside the K loop
+    NOVA_STAMP(1);
     read_bias();
     ktile(0, std::true_type{});
-    for (int kt = 1; kt < nkt; ++kt) ktile(kt, std::false_type{});
+    NOVA_STAMP(2);
+    for (int kt = 1; kt < nkt - 1; ++kt) ktile(kt, std::false_type{});
+    NOVA_STAMP(3);
+    if (nkt > 1) ktile(nkt - 1, std::false_type{});
+    NOVA_STAMP(4);
     if (wr == 0) NOVA_BARRIER();  // re-align the groups: every LDS slot is dead from here on
+    NOVA_STAMP(5);
 
     // ---- epilogue
     // (opaque copies: otherwise the row/table address arithmetic below is hoisted above the K loop and its
@@ -642,6 +667,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
         set_tile(m0, n0);
         stage_prologue(n0);
       }
+      NOVA_STAMP(6);
     };
     if constexpr (COLS8) {
       next_prologue();
@@ -662,12 +688,299 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
       q8_max = wave_max(q8_max);
       if (fresh_lane() == 0) __hip_atomic_fetch_max(e.q8_amax, __float_as_uint(q8_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    NOVA_STAMP(7);
+#ifdef NOVA_STAMPS
+    ++stamp_tile;
+#endif
     if (!more) break;
     first = false;
     it = nxt;
   }
+#ifdef NOVA_STAMPS
+  if (blockIdx.x == 0) {
+    __syncthreads();
+    for (int i = tid; i < 2 * STAMP_TILES * STAMP_PTS; i += 512) g_gemm_stamps[i] = reinterpret_cast<uint32_t*>(smem + P_LDS)[i];
+  }
+#endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Continuous form (round 4): the K-stream does not stop at a tile boundary. In-kernel stamps of the prologue form above
+// (tools/gemm_stamps.py, profiles/r04_gemm_stamps_prologue_form.txt) put 14-17k of a K = 1024 tile's 55-57k cycles into the seam,
+// whatever the epilogue computes, and show why: the next tile's first K-tiles are requested at the START of the epilogue, side by
+// side with its 16-32 stores per wave in the CU's one memory pipeline - the tile top waits for K-tile 0 queued behind stores
+// (2-6k cycles), K-tile 0 then runs at half speed because its own wait needs every older store retired (in-order vmcnt) while
+// K-tile 1 is still arriving, and re-ordering inside the seam only moves the time around (a barrier between the DMAs and the
+// stores: top wait 4.2k -> 1.8k, K loop + 2k).
+// Here the staging of the K loop simply carries on into the next tile: phase p of K-tile kt requests the unit that is 6 phases
+// ahead in the FLAT sequence of (tile, K-tile) pairs, so the last two K-tiles of a tile request K-tiles 0 and 1 of the next one
+// (same LDS slots, same distances, the same counted wait: nothing about the K loop's LDS protocol changes), wave 0 requests the
+// next tile's bias with them, and when a tile's last MFMA retires the next tile's first K-tile is already in LDS. The epilogue is
+// then VALU work and stores with no DMA beside them; there is no tile-top wait, no prologue, and the two wave groups stay one
+// barrier apart across tiles (no re-align / re-skew pair): each group's epilogue runs under the other group's MFMA phase.
+// The stores are retired by the first K-tile's ordinary wait (they are older than the units it covers).
+// Preconditions (launcher): an even number of K-tiles (buffer parity carries over) and at least 4 of them.
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ A, const T* __restrict__ W, T* __restrict__ C, int M,
+                                                          int N, int K, int ntm, int ntn, GemmEpi256 e) {
+  typedef T OT;
+  constexpr bool COLS8 = EPI != E_ROPE;  // column map of the X fragments (header comment)
+  __shared__ __attribute__((aligned(16))) char smem[P_LDS + P_STAMPS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  [[maybe_unused]] int stamp_tile = 0;
+
+  const int nwg = ntm * ntn;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int cq = nwg >> 3, cr = nwg & 7;
+  const int cbase = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+  const int csize = cq + (xcd < cr ? 1 : 0);
+  if (slot >= csize) return;  // workgroup-uniform, before any barrier
+
+  const int GM = e.gm;
+  const int per_group = GM * ntn;
+  auto tile_origin = [&](int t, int& m0, int& n0) {
+    const int group = t / per_group, first_m = group * GM;
+    const int gsz = min(ntm - first_m, GM);
+    m0 = (first_m + (t % per_group) % gsz) * 256;
+    n0 = ((t % per_group) / gsz) * 256;
+  };
+  auto fresh_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+  const size_t rowbytes = (size_t)K * sizeof(T);
+  // the tile being STAGED (the tile being computed until the switch in the second-to-last K-tile, the next one after it)
+  const char *a_base, *w_base;
+  uint32_t soff[4][2];
+  auto set_tile = [&](int m0, int n0) {
+    a_base = reinterpret_cast<const char*>(A) + (size_t)m0 * rowbytes;
+    w_base = reinterpret_cast<const char*>(W) + (size_t)n0 * rowbytes;
+    dma_offsets<COLS8>(fresh_lane(), wid, M - 1 - m0, (uint32_t)rowbytes, soff);
+  };
+  const int nkt = K / (128 / (int)sizeof(T));
+  auto unit_off = [](int u) { return (u == 0 ? 0 : u == 2 ? 1 : u == 3 ? 2 : 3) * P_UNIT; };
+  auto stage = [&](int u, int kt) {  // unit u of K-tile kt of the staged tile
+    char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048;
+    const char* base = ((u == 0 || u == 2) ? w_base : a_base) + (size_t)kt * 128;
+    __builtin_amdgcn_global_load_lds(base + soff[u][0], NOVA_LDS_PTR(dst), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(base + soff[u][1], NOVA_LDS_PTR(dst + 1024), 16, 0, 0);
+  };
+  const bool lds_bias = e.bias != nullptr;
+  auto stage_bias = [&](int n0) {  // the tile's 256 bias values -> LDS, by wave 0 (older than the units requested after it)
+    if (lds_bias && wid == 0)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(e.bias + n0) + lane * 16, NOVA_LDS_PTR(smem + P_BIAS), 16, 0, 0);
+  };
+
+  int fr, fg;
+  f4v acc[4][8];  // [y fragment][x fragment]
+  PFrag<T> xf[4][2], yf0[2][2], yf1[2][2];
+  auto read_x = [&](const char* buf, int xi) {
+    const char* u = buf + xi * P_UNIT;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) xf[f][kk] = punit_frag<T>(u, wr * 64 + f * 16 + fr, fg + 4 * kk);
+  };
+  auto read_y = [&](const char* buf, int yi, PFrag<T> (&yf)[2][2]) {
+    const char* u = buf + (2 + yi) * P_UNIT;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) yf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
+  };
+  f4v bcol[2];
+  auto mma_quadrant = [&](int xi, int yi, PFrag<T> (&yf)[2][2], auto first_ktile) {
+    constexpr bool FIRST = decltype(first_ktile)::value;
+    f4v c0[4];
+    if constexpr (FIRST) {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) c0[x] = f4v{bcol[xi][x], bcol[xi][x], bcol[xi][x], bcol[xi][x]};
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+          acc[yi * 2 + f][xi * 4 + x] = pmma(yf[f][kk], xf[x][kk], (FIRST && kk == 0) ? c0[x] : acc[yi * 2 + f][xi * 4 + x]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto read_bias = [&]() {
+#pragma unroll
+    for (int xi = 0; xi < 2; ++xi)
+      bcol[xi] = lds_bias ? *reinterpret_cast<const f4v*>(smem + P_BIAS + (wr * 128 + col_of<COLS8>(fr, xi)) * 4) : f4v{0.f, 0.f, 0.f, 0.f};
+  };
+
+  int m0, n0, nm0 = 0, nn0 = 0;
+  bool more = false;
+  // One K-tile = 4 phases (header comment). MODE 0: inside a tile (K-tiles 0 .. nkt-3): requests K-tiles kt+1, kt+2 of the same
+  // tile. MODE 1: the second-to-last K-tile: the staged tile switches to the next one between phases 1 and 2. MODE 2: the last
+  // K-tile: all four requests belong to the next tile. Without a next tile modes 1 / 2 request nothing and drain.
+  auto ktile = [&](int kt, auto first_ktile, auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const char* buf = smem + (kt & 1) * P_BUF;
+    read_x(buf, 0);
+    read_y(buf, 0, yf0);
+    if (MODE == 0 || MODE == 1) stage(2, kt + 1);
+    else if (more) stage(2, 0);
+    NOVA_BARRIER();
+    mma_quadrant(0, 0, yf0, first_ktile);
+    NOVA_BARRIER();
+    read_y(buf, 1, yf1);
+    if (MODE == 0 || MODE == 1) stage(3, kt + 1);
+    else if (more) stage(3, 0);
+    NOVA_BARRIER();
+    mma_quadrant(0, 1, yf1, first_ktile);
+    NOVA_BARRIER();
+    read_x(buf, 1);
+    if (MODE == 0) {
+      stage(0, kt + 2);
+    } else if (MODE == 1) {
+      if (more) {
+        set_tile(nm0, nn0);  // from here on the next tile is the staged one
+        stage_bias(nn0);
+        stage(0, 0);
+      }
+    } else if (more) {
+      stage(0, 1);
+    }
+    NOVA_BARRIER();
+    mma_quadrant(1, 1, yf1, first_ktile);
+    NOVA_BARRIER();
+    if (MODE == 0) {
+      stage(1, kt + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (MODE == 1) {
+      if (more) {
+        stage(1, 0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the last K-tile of this tile has landed (and, wave 0, the next bias)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else if (more) {
+      stage(1, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-tile 0 of the next tile has landed
+    }
+    NOVA_BARRIER();
+    mma_quadrant(1, 0, yf0, first_ktile);
+    NOVA_BARRIER();
+  };
+
+  if (e.stagger > 0) {
+    const long long until = clock64() + (long long)e.stagger * (int)blockIdx.x / (int)gridDim.x;
+    while (clock64() < until) __builtin_amdgcn_s_sleep(8);
+  }
+  int it = slot;
+  auto tile_at = [&](int i) { return cbase + (e.rev ? csize - 1 - i : i); };
+  tile_origin(tile_at(it), m0, n0);
+  set_tile(m0, n0);
+  stage_bias(n0);
+  stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
+  stage(0, 1); stage(1, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  NOVA_BARRIER();
+  if (wr == 1) NOVA_BARRIER();  // group 1 runs one barrier behind group 0 inside the K loop
+  for (;;) {
+    { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
+    NOVA_STAMP(0);
+    const int nxt = it + nslot;
+    more = nxt < csize;
+    if (more) tile_origin(tile_at(nxt), nm0, nn0);
+    read_bias();
+    NOVA_STAMP(1);
+    ktile(0, std::true_type{}, std::integral_constant<int, 0>{});
+    NOVA_STAMP(2);
+    for (int kt = 1; kt < nkt - 2; ++kt) ktile(kt, std::false_type{}, std::integral_constant<int, 0>{});
+    NOVA_STAMP(3);
+    ktile(nkt - 2, std::false_type{}, std::integral_constant<int, 1>{});
+    ktile(nkt - 1, std::false_type{}, std::integral_constant<int, 2>{});
+    NOVA_STAMP(4);
+    // Both groups run their epilogue at the same time (group 0 waits one barrier for group 1's last MFMA phase, group 1 spends
+    // one barrier after the epilogue to fall behind again). Left one barrier apart across the tile boundary the groups take
+    // turns - a group's epilogue holds the other one at its next barrier - and the seam is the SUM of the two epilogues
+    // (stamps: K-tile 0 of group 0 10.1k cycles, the last K-tile of group 1 13.5k, against 2.5k for an ordinary K-tile).
+    if (wr == 0) NOVA_BARRIER();
+    NOVA_STAMP(5);
+
+    // ---- epilogue of tile (m0, n0): no LDS traffic, no DMA issued beside it
+    int cm0 = m0, cn0 = n0;
+    asm volatile("" : "+s"(cm0), "+s"(cn0));
+    { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
+    const bool rot = EPI == E_ROPE && cn0 < e.rope_cols;
+    const float qmul = (EPI == E_ROPE && cn0 < e.q_cols) ? e.q_scale : 1.0f;  // tile-uniform; x * 1.0f is exact
+    const int nw = cn0 + wr * 128;  // the wave's first column; the lane's 4 columns of half xi start at nw + col_of(fr, xi)
+    f4v cs[4][4];  // RoPE table rows of the lane's 16 output rows: (cos0, sin0, cos1, sin1) of the pairs in its 4 columns
+    const bool same_cols = 64 % e.hd == 0;  // both 64-column halves of the wave see the same table columns (head_dim 64)
+    auto load_cs = [&](int xi) {
+      const int tcol = (nw + col_of<COLS8>(fr, xi)) % e.hd;
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+        const int mb = min(__builtin_amdgcn_readfirstlane(cm0 + wc * 64 + y * 16), M - 1);
+        const int s0 = mb / e.L, l0 = mb - s0 * e.L;
+        const int b0 = s0 % e.rope_batch, b1 = b0 + 1 == e.rope_batch ? 0 : b0 + 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int l = l0 + min(fg * 4 + r, M - 1 - mb);  // rows past M reuse row M-1 (never stored differently)
+          int sb = b0;
+          if (l >= e.L) { l -= e.L; sb = b1; }  // a 16-row block crosses at most one sequence boundary (L >= 16)
+          cs[y][r] = *reinterpret_cast<const f4v*>(e.rope + ((size_t)sb * e.L + l) * e.hd + tcol);
+        }
+      }
+    };
+    auto row_of = [&](int y, int r) { return min(cm0 + wc * 64 + y * 16 + fg * 4 + r, M - 1); };  // rows past M: copies of row M-1
+    auto value4 = [&](int y, int r, int xi) { return f4v{acc[y][xi * 4][r], acc[y][xi * 4 + 1][r], acc[y][xi * 4 + 2][r], acc[y][xi * 4 + 3][r]}; };
+    auto finish_half = [&](int xi, auto rotated) {
+      constexpr bool ROT = decltype(rotated)::value;
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          store4<OT>(C + (size_t)row_of(y, r) * N + nw + col_of<false>(fr, xi), epi_apply<OT, EPI, ROT>(value4(y, r, xi), cs[y][r], qmul));
+    };
+    NOVA_STAMP(6);
+    if constexpr (COLS8) {
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f4v lo = value4(y, r, 0), hi = value4(y, r, 1);
+          store8<OT>(C + (size_t)row_of(y, r) * N + nw + fr * 8, epi_apply<OT, EPI, false>(lo, lo, qmul), epi_apply<OT, EPI, false>(hi, hi, qmul));
+        }
+    } else if (rot) {
+      load_cs(0);  // (the compiler waits for everything in flight at their first use: the two units of the next tile's K-tile 1)
+      finish_half(0, std::true_type{});
+      if (!same_cols) load_cs(1);
+      finish_half(1, std::true_type{});
+    } else {
+      finish_half(0, std::false_type{});
+      finish_half(1, std::false_type{});
+    }
+    NOVA_STAMP(7);
+#ifdef NOVA_STAMPS
+    ++stamp_tile;
+#endif
+    if (!more) break;
+    if (wr == 1) NOVA_BARRIER();  // one barrier behind group 0 again
+    it = nxt;
+    m0 = nm0;
+    n0 = nn0;
+  }
+#ifdef NOVA_STAMPS
+  if (blockIdx.x == 0) {
+    __syncthreads();
+    for (int i = tid; i < 2 * STAMP_TILES * STAMP_PTS; i += 512) g_gemm_stamps[i] = reinterpret_cast<uint32_t*>(smem + P_LDS)[i];
+  }
+#endif
+}
+
+#ifdef NOVA_STAMPS
+}  // namespace nova
+extern "C" int nova_debug_gemm_stamps(unsigned* out, int n) {  // diagnostic build only: the record of the last persistent launch
+  const int m = n < 2 * nova::STAMP_TILES * nova::STAMP_PTS ? n : 2 * nova::STAMP_TILES * nova::STAMP_PTS;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nova::g_gemm_stamps), (size_t)m * 4, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+namespace nova {
+#endif
 #ifdef NOVA_EXPERIMENTS
 static int g_gm256 = 8;
 static int g_stagger256 = 0;
@@ -772,10 +1085,35 @@ int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const fl
 }
 
 template <typename T>
+static int launch256c(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
+                      hipStream_t st) {
+  const int ntm = (M + 255) / 256, ntn = N / 256;
+  dim3 grid(cu_slots()), block(512);
+  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  const T* a = static_cast<const T*>(A);
+  const T* w = static_cast<const T*>(W);
+  T* c = static_cast<T*>(C);
+  switch (epi) {
+    case E_NONE: hipLaunchKernelGGL((gemm256c_kernel<T, E_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_GELU: hipLaunchKernelGGL((gemm256c_kernel<T, E_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_SILU: hipLaunchKernelGGL((gemm256c_kernel<T, E_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_ROPE: hipLaunchKernelGGL((gemm256c_kernel<T, E_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    default: return set_error(NOVA_ERR_ARG, "gemm256: unknown epilogue %d", epi);
+  }
+  return check_launch("gemm256c");
+}
+
+// form: 0 = the shipped choice (continuous form where its preconditions hold, else the prologue form), 1 = one tile per
+// workgroup, 2 = the persistent prologue form (nova_debug_force_gemm_tile 257 / 258: A/B and the bitwise tests)
+template <typename T>
 static int launch256(const void* A, const void* W, void* C, int M, int N, int K, int epi, const GemmEpi256& e,
-                     hipStream_t st, bool single) {
-  // (the persistent RoPE epilogue steps through a 16-row block assuming it crosses at most one sequence boundary)
-  if (!single && g_var256 == 20 && !(epi == E_ROPE && e.rope && e.L < 16)) return launch256p<T>(A, W, C, M, N, K, epi, e, st);
+                     hipStream_t st, int form) {
+  // (the persistent RoPE epilogues step through a 16-row block assuming it crosses at most one sequence boundary)
+  if (form != 1 && g_var256 == 20 && !(epi == E_ROPE && e.rope && e.L < 16)) {
+    const int nkt = K / (128 / (int)sizeof(T));
+    if (form == 0 && nkt >= 4 && (nkt & 1) == 0) return launch256c<T>(A, W, C, M, N, K, epi, e, st);
+    return launch256p<T>(A, W, C, M, N, K, epi, e, st);
+  }
 #ifdef NOVA_EXPERIMENTS
   switch (g_var256) {
     case 1: return launch256v<T, 1>(A, W, C, M, N, K, epi, e, st);
@@ -794,9 +1132,9 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
 // K % (128 / sizeof(T)) == 0, K > 0, M > 0.
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
-                   hipStream_t st, bool one_tile_per_workgroup) {
+                   hipStream_t st, int form) {
   GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, walk_is_reverse() ? 1 : 0, nullptr, nullptr, g_stagger256};
-  return dispatch_dtype(dtype, [&](auto tag) { return launch256<decltype(tag)>(A, W, C, M, N, K, epi, e, st, one_tile_per_workgroup); });
+  return dispatch_dtype(dtype, [&](auto tag) { return launch256<decltype(tag)>(A, W, C, M, N, K, epi, e, st, form); });
 }
 
 }  // namespace nova

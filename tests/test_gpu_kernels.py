@@ -295,7 +295,7 @@ def test_decoder_glue(hip, dtype):
 # ---------------------------------------------------------------------------------------------
 # the two 256x256 structures: one tile per workgroup (2560 + 2: its shipped schedule variant) and the persistent
 # one-workgroup-per-CU form (2560 + 20)
-TILE256_FORMS = [257, 256]  # one tile per workgroup (fallback form), persistent (default form)
+TILE256_FORMS = [257, 258, 256]  # one tile per workgroup, persistent with a per-tile prologue (fallback forms), the shipped choice (continuous K-stream where K allows)
 
 
 @pytest.fixture()
