@@ -51,9 +51,11 @@ int nova_check_device(void);
  * the stream they are launched on. nova_prof_enable(1) starts recording; nova_prof_collect waits
  * for the recorded events and returns, per slot, summed milliseconds, summed algorithmic work
  * (FLOPs for slots 0-4 and 6, bytes for slot 5) and launch counts, then clears the record.
- * Slots 0-3: the large-M (256x256 tile) GEMM kernel by epilogue - 0 bias, 1 bias+GELU, 2 bias+SiLU, 3 qkv+RoPE;
- * 4 attention, 5 row_norm, 6 the small-M (128x128 tile) GEMM kernel with any epilogue (decoder, embeddings). */
-#define NOVA_PROF_SLOTS 7
+ * Slots 0-3: the large-M (256x256 tile) GEMM kernel by epilogue - 0 bias with K <= N (the out-projection), 1 bias+GELU, 2 bias+SiLU,
+ * 3 qkv+RoPE; 4 attention, 5 row_norm, 6 the small-M (128x128 tile / whole-K) GEMM kernels with any epilogue (decoder, embeddings),
+ * 7 the large-M GEMM, bias only, K > N (the MLP's second projection), 8 token plumbing (canvas embedding, sequence build / scatter,
+ * RoPE table, KV append, frame mixer, fp8 row quantisation; work = 0), 9 the diffusion MLP's glue kernels (work = 0). */
+#define NOVA_PROF_SLOTS 10
 int nova_prof_enable(int on);
 int nova_prof_collect(double* ms, double* work, long long* launches, int slots);
 
@@ -124,7 +126,11 @@ int nova_rope_table(const float* pos, const long long* ids, float* rope, int nb,
  * Element (s, l, head, c) of q lives at q + (s*Lq + l)*q_row_stride + head*head_dim + c (same
  * for k/v with Lk / kv_row_stride, o with o_row_stride); strides in elements, 16-byte multiples.
  * Replaces F.scaled_dot_product_attention at vision_transformer.py:63 and the
- * transpose(1,2).flatten(2) merge at :64. head_dim 64 (d48w768, d48w1024) and 96 (d48w1536) are built. */
+ * transpose(1,2).flatten(2) merge at :64. head_dim 64 (d48w768, d48w1024) and 96 (d48w1536) are built.
+ * Non-finite inputs: the 16-bit kernels are compiled without NaN-honouring max / compare instructions. A query row whose scores
+ * contain a NaN or overflow to +inf yields a non-finite output row (as SDPA's softmax would); all other output rows are
+ * bit for bit those of the same call without the offending values (tests/test_gpu_kernels.py::
+ * test_attention_non_finite_rows_stay_in_their_row). -inf scores do not occur (no mask input). */
 int nova_attn_fwd(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int head_dim,
                   long q_row_stride, long kv_row_stride, long o_row_stride, float scale, int dtype, void* stream);
 

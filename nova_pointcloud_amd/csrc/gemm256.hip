@@ -720,16 +720,25 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const T* __restrict__ 
 // barrier apart across tiles (no re-align / re-skew pair): each group's epilogue runs under the other group's MFMA phase.
 // The stores are retired by the first K-tile's ordinary wait (they are older than the units it covers).
 // Preconditions (launcher): an even number of K-tiles (buffer parity carries over) and at least 4 of them.
-template <typename T, int EPI>
+template <typename T, int EPI, bool TDMA = false>
 __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ A, const T* __restrict__ W, T* __restrict__ C, int M,
                                                           int N, int K, int ntm, int ntn, GemmEpi256 e) {
   typedef T OT;
-  constexpr bool COLS8 = EPI != E_ROPE;  // column map of the X fragments (header comment)
-  __shared__ __attribute__((aligned(16))) char smem[P_LDS + P_STAMPS];
+  static_assert(!TDMA || EPI == E_ROPE, "the table-through-LDS form belongs to the RoPE epilogue");
+  // TDMA (RoPE, head width 64): the cos / sin rows come through LDS - each wave brings the 16 table rows of one Y fragment
+  // (16 x 256 B) into a window of its own by LDS-DMA, one fragment ahead of the one it is rotating, and reads them back with
+  // ds_read_b128. Through registers the rows are 16-32 global loads per lane and tile at ~75 cycles of the CU's memory pipeline
+  // each (tools/ta_probe.hip) - with the stores, 15k cycles of pipeline time per tile, which IS the epilogue of the fused-QKV
+  // GEMM once the prologue is out of it; an LDS-DMA instruction moves the same kilobyte in 21-33. The windows take the 32 KiB
+  // beside the K-tile buffers (so the bias travels in registers in this form) and, since the table is read from LDS, the lane
+  // can hold 8 consecutive columns (16-byte stores) like every other epilogue.
+  constexpr bool COLS8 = EPI != E_ROPE || TDMA;  // column map of the X fragments (header comment)
+  constexpr int P_TAB = P_KLDS;                   // TDMA: 8 wave windows of 4 KiB
+  __shared__ __attribute__((aligned(16))) char smem[TDMA ? P_KLDS + 8 * 4096 : P_LDS + P_STAMPS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-  [[maybe_unused]] int stamp_tile = 0;
+  [[maybe_unused]] int stamp_tile = TDMA ? 1 << 20 : 0;  // (no stamp record in the TDMA form: its LDS is full)
 
   const int nwg = ntm * ntn;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
@@ -764,7 +773,7 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
     __builtin_amdgcn_global_load_lds(base + soff[u][0], NOVA_LDS_PTR(dst), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(base + soff[u][1], NOVA_LDS_PTR(dst + 1024), 16, 0, 0);
   };
-  const bool lds_bias = e.bias != nullptr;
+  const bool lds_bias = !TDMA && e.bias != nullptr;
   auto stage_bias = [&](int n0) {  // the tile's 256 bias values -> LDS, by wave 0 (older than the units requested after it)
     if (lds_bias && wid == 0)
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(e.bias + n0) + lane * 16, NOVA_LDS_PTR(smem + P_BIAS), 16, 0, 0);
@@ -788,6 +797,20 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
       for (int kk = 0; kk < 2; ++kk) yf[f][kk] = punit_frag<T>(u, wc * 32 + f * 16 + fr, fg + 4 * kk);
   };
   f4v bcol[2];
+  // TDMA: the table rows of Y fragment y of tile rows m0 + wc*64 + 16 y + [0, 16) -> this wave's window (4 instructions of 4 rows)
+  auto stage_table = [&](int m0, int y) {
+    const int mb = min(__builtin_amdgcn_readfirstlane(m0 + wc * 64 + y * 16), M - 1);
+    const int s0 = mb / e.L, l0 = mb - s0 * e.L;
+    const int b0 = s0 % e.rope_batch, b1 = b0 + 1 == e.rope_batch ? 0 : b0 + 1;
+    const int ln = fresh_lane();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int l = l0 + min(i * 4 + (ln >> 4), M - 1 - mb);  // rows past M reuse row M-1
+      int sb = b0;
+      if (l >= e.L) { l -= e.L; sb = b1; }  // a 16-row block crosses at most one sequence boundary (L >= 16)
+      __builtin_amdgcn_global_load_lds(e.rope + ((size_t)sb * e.L + l) * 64 + (ln & 15) * 4, NOVA_LDS_PTR(smem + P_TAB + wid * 4096 + i * 1024), 16, 0, 0);
+    }
+  };
   auto mma_quadrant = [&](int xi, int yi, PFrag<T> (&yf)[2][2], auto first_ktile) {
     constexpr bool FIRST = decltype(first_ktile)::value;
     f4v c0[4];
@@ -806,6 +829,7 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
     __builtin_amdgcn_s_setprio(0);
   };
   auto read_bias = [&]() {
+    if constexpr (TDMA) return;  // in registers since the previous epilogue (or the kernel entry)
 #pragma unroll
     for (int xi = 0; xi < 2; ++xi)
       bcol[xi] = lds_bias ? *reinterpret_cast<const f4v*>(smem + P_BIAS + (wr * 128 + col_of<COLS8>(fr, xi)) * 4) : f4v{0.f, 0.f, 0.f, 0.f};
@@ -861,6 +885,9 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
       stage(1, 1);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // K-tile 0 of the next tile has landed
     }
+    if constexpr (TDMA && MODE == 2) {
+      if (n0 < e.rope_cols) stage_table(m0, 0);  // behind the wait: the first fragment's table rows arrive under this tile's last MFMAs
+    }
     NOVA_BARRIER();
     mma_quadrant(1, 0, yf0, first_ktile);
     NOVA_BARRIER();
@@ -874,6 +901,14 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
   auto tile_at = [&](int i) { return cbase + (e.rev ? csize - 1 - i : i); };
   tile_origin(tile_at(it), m0, n0);
   set_tile(m0, n0);
+  auto load_bias_regs = [&](int n0) {  // TDMA: the lane's 8 bias values by ordinary loads, waited for on the spot (nothing else in flight)
+    const int f = fresh_lane() & 15;
+#pragma unroll
+    for (int xi = 0; xi < 2; ++xi)
+      bcol[xi] = e.bias ? *reinterpret_cast<const f4v*>(e.bias + n0 + wr * 128 + col_of<COLS8>(f, xi)) : f4v{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(bcol[0]), "+v"(bcol[1]));
+  };
+  if constexpr (TDMA) load_bias_regs(n0);
   stage_bias(n0);
   stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0);
   stage(0, 1); stage(1, 1);
@@ -907,7 +942,6 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
     asm volatile("" : "+s"(cm0), "+s"(cn0));
     { const int l = fresh_lane(); fr = l & 15; fg = l >> 4; }
     const bool rot = EPI == E_ROPE && cn0 < e.rope_cols;
-    const float qmul = (EPI == E_ROPE && cn0 < e.q_cols) ? e.q_scale : 1.0f;  // tile-uniform; x * 1.0f is exact
     const int nw = cn0 + wr * 128;  // the wave's first column; the lane's 4 columns of half xi start at nw + col_of(fr, xi)
     f4v cs[4][4];  // RoPE table rows of the lane's 16 output rows: (cos0, sin0, cos1, sin1) of the pairs in its 4 columns
     const bool same_cols = 64 % e.hd == 0;  // both 64-column halves of the wave see the same table columns (head_dim 64)
@@ -927,33 +961,97 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
         }
       }
     };
-    auto row_of = [&](int y, int r) { return min(cm0 + wc * 64 + y * 16 + fg * 4 + r, M - 1); };  // rows past M: copies of row M-1
+    // Output addressing: a wave-uniform 64-bit tile base + a 32-bit lane offset per row (rows past M are copies of row M-1 and store
+    // the identical bytes there again, so every tile issues the same number of stores)
+    OT* const ctile = C + (size_t)cm0 * N + nw;
+    const int rlim = M - 1 - cm0;
+    auto row_off = [&](int y, int r) { return (uint32_t)min(wc * 64 + y * 16 + fg * 4 + r, rlim) * (uint32_t)N; };
+    // 4 / 8 consecutive columns of output row (y, r): component r of 4 / 8 accumulators. The packing instruction takes any two
+    // registers, so nothing has to be moved together first.
+    auto put4 = [&](int y, int r, int xi, f4v v) { store4<OT>(ctile + row_off(y, r) + col_of<false>(fr, xi), v); };
     auto value4 = [&](int y, int r, int xi) { return f4v{acc[y][xi * 4][r], acc[y][xi * 4 + 1][r], acc[y][xi * 4 + 2][r], acc[y][xi * 4 + 3][r]}; };
-    auto finish_half = [&](int xi, auto rotated) {
-      constexpr bool ROT = decltype(rotated)::value;
+    auto put8 = [&](int y, int r, f4v lo, f4v hi) { store8<OT>(ctile + row_off(y, r) + fr * 8, lo, hi); };
+    // The elementwise epilogues run IN PLACE on the accumulators, one register quad (4 rows of one column) at a time: the packed
+    // f32 forms (v_pk_mul / v_pk_fma, gelu_erf_fast4) take aligned register pairs, and applied to the per-row gathers of the
+    // stores below they cost one v_mov per operand pair on top (194 moves in 1096 vector instructions of the fc1 epilogue).
+    if constexpr (EPI == E_GELU || EPI == E_SILU) {
 #pragma unroll
       for (int y = 0; y < 4; ++y)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          store4<OT>(C + (size_t)row_of(y, r) * N + nw + col_of<false>(fr, xi), epi_apply<OT, EPI, ROT>(value4(y, r, xi), cs[y][r], qmul));
+        for (int x = 0; x < 8; ++x) acc[y][x] = epi_apply<OT, EPI, false>(acc[y][x], acc[y][x], 1.0f);
+    }
+    const bool qs = EPI == E_ROPE && cn0 < e.q_cols;  // a q tile: results times the softmax scale (after the rotation)
+    if (EPI == E_ROPE && qs && !rot) {  // (not a combination the model produces: q columns are rotated)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc[y][x] = acc[y][x] * e.q_scale;
+    }
+    auto rotated = [&](f4v v, f4v t, auto scaled) {  // pair rotation, then (q tiles) the scale: the order every GEMM structure rounds in
+      v = rope_rotate4(v, t);
+      if constexpr (decltype(scaled)::value) v = v * e.q_scale;
+      return v;
     };
-    NOVA_STAMP(6);
-    if constexpr (COLS8) {
+    const float qmul = qs ? e.q_scale : 1.0f;  // x * 1.0f is exact
+    auto finish_half = [&](int xi) {  // 4-column map, rotated tile (one code path: this form holds 64 table registers)
+#pragma unroll
+      for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put4(y, r, xi, rope_rotate4(value4(y, r, xi), cs[y][r]) * qmul);
+    };
+    auto plain_rows = [&]() {  // no rotation: the accumulators as they stand
 #pragma unroll
       for (int y = 0; y < 4; ++y)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const f4v lo = value4(y, r, 0), hi = value4(y, r, 1);
-          store8<OT>(C + (size_t)row_of(y, r) * N + nw + fr * 8, epi_apply<OT, EPI, false>(lo, lo, qmul), epi_apply<OT, EPI, false>(hi, hi, qmul));
+          if constexpr (COLS8) {
+            put8(y, r, value4(y, r, 0), value4(y, r, 1));
+          } else {
+            put4(y, r, 0, value4(y, r, 0));
+            put4(y, r, 1, value4(y, r, 1));
+          }
         }
+    };
+    NOVA_STAMP(6);
+    if constexpr (TDMA) {
+      // everything in flight lands here: the two units of the next tile's K-tile 1 and, youngest, table fragment 0; then the
+      // next tile's bias (requested and consumed on the spot, so that no later use of it waits for this epilogue's stores)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (more) load_bias_regs(nn0);
+      if (rot) {
+        constexpr int ST = sizeof(OT) == 2 ? 4 : 8;  // stores of one fragment pass
+        const char* win = smem + P_TAB + wid * 4096 + (fr & 7) * 32;  // both heads of the wave's 128 columns use the same 64 table floats
+        auto passes = [&](auto scaled) {
+#pragma unroll
+          for (int y = 0; y < 4; ++y) {
+            if (y > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST) : "memory");  // fragment y's rows landed (the previous pass's stores may be in flight)
+            f4v tlo[4], thi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              tlo[r] = *reinterpret_cast<const f4v*>(win + (fg * 4 + r) * 256);
+              thi[r] = *reinterpret_cast<const f4v*>(win + (fg * 4 + r) * 256 + 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the window is read: the next fragment's rows may overwrite it
+            __builtin_amdgcn_sched_barrier(0);
+            if (y < 3) stage_table(cm0, y + 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) put8(y, r, rotated(value4(y, r, 0), tlo[r], scaled), rotated(value4(y, r, 1), thi[r], scaled));
+          }
+        };
+        if (qs) passes(std::true_type{});
+        else passes(std::false_type{});
+      } else {
+        plain_rows();
+      }
+    } else if constexpr (COLS8) {
+      plain_rows();
     } else if (rot) {
       load_cs(0);  // (the compiler waits for everything in flight at their first use: the two units of the next tile's K-tile 1)
-      finish_half(0, std::true_type{});
+      finish_half(0);
       if (!same_cols) load_cs(1);
-      finish_half(1, std::true_type{});
+      finish_half(1);
     } else {
-      finish_half(0, std::false_type{});
-      finish_half(1, std::false_type{});
+      plain_rows();
     }
     NOVA_STAMP(7);
 #ifdef NOVA_STAMPS
@@ -966,7 +1064,7 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
     n0 = nn0;
   }
 #ifdef NOVA_STAMPS
-  if (blockIdx.x == 0) {
+  if (!TDMA && blockIdx.x == 0) {
     __syncthreads();
     for (int i = tid; i < 2 * STAMP_TILES * STAMP_PTS; i += 512) g_gemm_stamps[i] = reinterpret_cast<uint32_t*>(smem + P_LDS)[i];
   }
@@ -999,7 +1097,7 @@ static int launch256v(const void* A, const void* W, void* C, int M, int N, int K
                      hipStream_t st) {
   const int ntm = (M + 255) / 256, ntn = N / 256;
   dim3 grid(ntm * ntn), block(512);
-  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  ProfScope prof(prof_gemm_slot(epi, N, K), 2.0 * M * N * K, st);
   const T* a = static_cast<const T*>(A);
   const T* w = static_cast<const T*>(W);
   T* c = static_cast<T*>(C);
@@ -1037,7 +1135,7 @@ static int launch256p(const void* A, const void* W, void* C, int M, int N, int K
                       hipStream_t st) {
   const int ntm = (M + 255) / 256, ntn = N / 256;
   dim3 grid(cu_slots()), block(512);
-  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  ProfScope prof(prof_gemm_slot(epi, N, K), 2.0 * M * N * K, st);
   const T* a = static_cast<const T*>(A);
   const T* w = static_cast<const T*>(W);
   T* c = static_cast<T*>(C);
@@ -1069,7 +1167,7 @@ int gemm256_fp8_launch(const void* A8, const float* sa, const void* W8, const fl
   if (epi == E_GELU_Q8 && (!q8_scale || !q8_amax)) return set_error(NOVA_ERR_ARG, "gemm_fp8: the e4m3-output epilogue needs a scale and an amax word");
   const int ntm = (M + 255) / 256, ntn = N / 256;
   dim3 grid(cu_slots()), block(512);
-  ProfScope prof(PROF_GEMM_NONE + (epi == E_GELU_Q8 ? E_GELU : epi), 2.0 * M * N * K, st);
+  ProfScope prof(prof_gemm_slot(epi == E_GELU_Q8 ? E_GELU : epi, N, K), 2.0 * M * N * K, st);
   const fp8_t* a = static_cast<const fp8_t*>(A8);
   const fp8_t* w = static_cast<const fp8_t*>(W8);
   bf16_t* c = static_cast<bf16_t*>(C);
@@ -1089,7 +1187,7 @@ static int launch256c(const void* A, const void* W, void* C, int M, int N, int K
                       hipStream_t st) {
   const int ntm = (M + 255) / 256, ntn = N / 256;
   dim3 grid(cu_slots()), block(512);
-  ProfScope prof(PROF_GEMM_NONE + epi, 2.0 * M * N * K, st);
+  ProfScope prof(prof_gemm_slot(epi, N, K), 2.0 * M * N * K, st);
   const T* a = static_cast<const T*>(A);
   const T* w = static_cast<const T*>(W);
   T* c = static_cast<T*>(C);
@@ -1097,7 +1195,12 @@ static int launch256c(const void* A, const void* W, void* C, int M, int N, int K
     case E_NONE: hipLaunchKernelGGL((gemm256c_kernel<T, E_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     case E_GELU: hipLaunchKernelGGL((gemm256c_kernel<T, E_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     case E_SILU: hipLaunchKernelGGL((gemm256c_kernel<T, E_SILU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
-    case E_ROPE: hipLaunchKernelGGL((gemm256c_kernel<T, E_ROPE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+    case E_ROPE:
+      // head width 64 with a table: the table rows through LDS and 8 consecutive columns per lane; other head widths (96: d48w1536)
+      // and the table-less q-scale-only use: table rows through registers, 4 consecutive columns per lane and column half
+      if (e.rope && e.hd == 64) hipLaunchKernelGGL((gemm256c_kernel<T, E_ROPE, true>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e);
+      else hipLaunchKernelGGL((gemm256c_kernel<T, E_ROPE, false>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e);
+      break;
     default: return set_error(NOVA_ERR_ARG, "gemm256: unknown epilogue %d", epi);
   }
   return check_launch("gemm256c");
@@ -1133,7 +1236,14 @@ static int launch256(const void* A, const void* W, void* C, int M, int N, int K,
 int gemm256_launch(const void* A, const void* W, void* C, int M, int N, int K, int epi, const float* bias,
                    const float* rope, int L, int rope_batch, int hd, int rope_cols, float q_scale, int q_cols, int dtype,
                    hipStream_t st, int form) {
-  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, g_gm256, walk_is_reverse() ? 1 : 0, nullptr, nullptr, g_stagger256};
+#ifdef NOVA_EXPERIMENTS
+  const int gm = g_gm256;
+#else
+  // row panels per tile group: 8 (the L2-hit maximum of round 3's sweep), 16 where a row of tiles is at most 4 wide and K is short
+  // (the out-projection: 0.282 against 0.294 ms at 163840 x 1024 x 1024; K = 4096 loses 6 % with 16: profiles/r04_gemm_group_height_sweep.txt)
+  const int gm = (N <= 1024 && K * (int)(dtype_is16(dtype) ? 2 : 4) <= 2048) ? 16 : g_gm256;
+#endif
+  GemmEpi256 e{bias, rope, L, rope_batch, hd, rope_cols, q_scale, q_cols, gm, walk_is_reverse() ? 1 : 0, nullptr, nullptr, g_stagger256};
   return dispatch_dtype(dtype, [&](auto tag) { return launch256<decltype(tag)>(A, W, C, M, N, K, epi, e, st, form); });
 }
 

@@ -24,8 +24,14 @@ int check_launch(const char* what);
 
 // ---- optional per-kernel timing with HIP events on the launch stream (capi.hip). Slots: one per
 // kernel family; `work` = algorithmic FLOPs (or bytes) of the launch. No-ops unless enabled.
-// PROF_GEMM_* : the 256x256 (large-M, encoder) GEMM kernels by epilogue; PROF_GEMM_SMALL: the 128x128 kernel, any epilogue
-enum { PROF_GEMM_NONE = 0, PROF_GEMM_GELU, PROF_GEMM_SILU, PROF_GEMM_ROPE, PROF_ATTN, PROF_ROWNORM, PROF_GEMM_SMALL, PROF_SLOTS };
+// PROF_GEMM_* : the 256x256 (large-M, encoder) GEMM kernels by epilogue (PROF_GEMM_NONE: bias-only launches with K <= N, the
+// out-projection; PROF_GEMM_WIDEK: bias-only launches with K > N, the MLP's second projection); PROF_GEMM_SMALL: the 128x128 and
+// small-M kernels, any epilogue; PROF_TOKENS: the token plumbing of the split encoder (canvas embedding, sequence build / scatter,
+// RoPE table, KV append, frame mixer, fp8 row quantisation); PROF_DECODER: the diffusion MLP's glue kernels (timestep features,
+// SiLU-add, patch embedding of the predicted rows, head + guidance + sampler step)
+enum { PROF_GEMM_NONE = 0, PROF_GEMM_GELU, PROF_GEMM_SILU, PROF_GEMM_ROPE, PROF_ATTN, PROF_ROWNORM, PROF_GEMM_SMALL, PROF_GEMM_WIDEK,
+       PROF_TOKENS, PROF_DECODER, PROF_SLOTS };
+inline int prof_gemm_slot(int epi, int N, int K) { return epi == 0 && K > N ? PROF_GEMM_WIDEK : PROF_GEMM_NONE + epi; }
 struct ProfScope {
   ProfScope(int slot, double work, hipStream_t st);
   ~ProfScope();

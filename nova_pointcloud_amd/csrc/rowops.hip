@@ -205,6 +205,7 @@ __global__ void rope_table_kernel(const float* __restrict__ pos, const long long
 
 int rope_table(const float* pos, const long long* ids, float* table, int nb, int pad, int n_tok, int n_pos, int hd,
                const float* inv_freq, hipStream_t st) {
+  ProfScope prof(PROF_TOKENS, 0.0, st);
   const long total = (long)nb * (pad + n_tok) * (hd / 2);
   if (total <= 0) return 0;
   const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(256) void embed_canvas_kernel(const float* __restri
 
 int embed_canvas(const float* canvas, const float* mask, const void* w, const float* bias, const void* mask_token,
                  const void* pos_embed, void* z0, int B, int N, int P, int D, int dtype, hipStream_t st) {
+  ProfScope prof(PROF_TOKENS, 0.0, st);
   if ((long)B * N <= 0) return 0;
   if (P > 64 || P <= 0) return set_error(NOVA_ERR_SHAPE, "embed_canvas: patch vector length %d unsupported (1..64)", P);
   dim3 grid((unsigned)((long)B * N)), block(256);
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(256) void build_sequence_kernel(const T* __restrict
 
 int build_sequence(const void* prefix, long prefix_seq_rows, const void* tokens, long tok_batch_rows,
                    const long long* ids, void* x, int S, int B, int Lp, int n_sel, int D, int dtype, hipStream_t st) {
+  ProfScope prof(PROF_TOKENS, 0.0, st);
   const long rows = (long)S * (Lp + n_sel);
   if (rows <= 0) return 0;
   const int V = dtype_is16(dtype) ? 8 : 4;
@@ -311,6 +314,7 @@ __global__ __launch_bounds__(256) void scatter_tokens_kernel(const T* __restrict
 
 int scatter_tokens(const void* x1, const long long* ids, void* x2, int S, int B, int Lp, int N, int n_prev, int D,
                    int dtype, hipStream_t st) {
+  ProfScope prof(PROF_TOKENS, 0.0, st);
   const long rows = (long)S * n_prev;
   if (rows <= 0) return 0;
   const int V = dtype_is16(dtype) ? 8 : 4;
@@ -388,6 +392,7 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __
 }
 
 int quantize_rows_fp8(const void* x, void* out, float* scale, long rows, int D, hipStream_t st) {
+  ProfScope prof(PROF_TOKENS, 0.0, st);
   if (rows <= 0) return 0;
   if (D % 8 != 0 || D > 8192) return set_error(NOVA_ERR_SHAPE, "quantize_rows_fp8: need D %% 8 == 0 and D <= 8192 (got %d)", D);
   hipLaunchKernelGGL(quantize_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, (uint8_t*)out, scale,
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(256) void silu_add_steps_kernel(const T* __restrict
 }
 
 int silu_add_steps(const void* a, const void* vecs, void* out, long rows, int nvec, int D, int dtype, hipStream_t st) {
+  ProfScope prof(PROF_DECODER, 0.0, st);
   if (rows <= 0 || nvec <= 0) return 0;
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "silu_add_steps: D %% 4 != 0");
   const long per4 = rows * D / 4, total4 = per4 * nvec;
@@ -424,6 +430,7 @@ int silu_add_steps(const void* a, const void* vecs, void* out, long rows, int nv
 }
 
 int silu_add_rows(const void* a, const void* rowvec, void* out, long rows, int D, int dtype, hipStream_t st) {
+  ProfScope prof(PROF_DECODER, 0.0, st);
   if (rows <= 0) return 0;
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "silu_add_rows: D %% 4 != 0");
   const long total4 = rows * D / 4;
@@ -450,6 +457,7 @@ __global__ void timestep_freq_kernel(const float* __restrict__ t, const float* _
 }
 
 int timestep_freq(const float* t, const float* freq, void* out, int n, int freq_dim, int dtype, hipStream_t st) {
+  ProfScope prof(PROF_DECODER, 0.0, st);
   if (n <= 0) return 0;
   const int total = n * (freq_dim / 2);
   dispatch_dtype(dtype, [&](auto tag) {
@@ -480,6 +488,7 @@ __global__ __launch_bounds__(256) void patch_embed_rows_kernel(const float* __re
 
 int patch_embed_rows(const float* x, const void* w, const float* bias, void* out, int S, int B, int n, int P, int D,
                      int dtype, hipStream_t st) {
+  ProfScope prof(PROF_DECODER, 0.0, st);
   if ((long)S * n <= 0) return 0;
   if (P > 64 || P <= 0) return set_error(NOVA_ERR_SHAPE, "patch_embed_rows: patch vector length %d unsupported", P);
   dim3 grid((unsigned)((long)S * n)), block(256);
@@ -565,6 +574,7 @@ __global__ __launch_bounds__(256) void head_cfg_step_kernel(const T* __restrict_
 
 int head_cfg_step(const void* h, const void* w, const float* bias, float* x, const float* noise, float* vhat, float* cond,
                   float* extra, int B, int n, int P, int D, const SamplerStep& sp, int defer, int dtype, hipStream_t st) {
+  ProfScope prof(PROF_DECODER, 0.0, st);
   const long rows = (long)B * n;
   if (rows <= 0) return 0;
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "head_cfg_step: D %% 4 != 0");
@@ -621,6 +631,7 @@ __global__ void scale_vector_kernel(float* v, int n, float f) {
 }
 
 int scale_vector(float* v, int n, float f, hipStream_t st) {
+  ProfScope prof(PROF_DECODER, 0.0, st);
   if (n <= 0) return 0;
   hipLaunchKernelGGL(scale_vector_kernel, dim3((n + 255) / 256), dim3(256), 0, st, v, n, f);
   return check_launch("scale_vector");
@@ -628,6 +639,7 @@ int scale_vector(float* v, int n, float f, hipStream_t st) {
 
 int renorm_euler(float* x, const float* vhat, const float* cond, const float* extra, float* echo, int B, int n, int P, float dt,
                  float renorm, hipStream_t st) {
+  ProfScope prof(PROF_DECODER, 0.0, st);
   if (B <= 0 || n <= 0) return 0;
   hipLaunchKernelGGL(renorm_euler_kernel, dim3(B), dim3(256), 0, st, x, vhat, cond, extra, echo, n * P, dt, renorm);
   return check_launch("renorm_euler");
@@ -651,6 +663,7 @@ __global__ __launch_bounds__(256) void kv_append_kernel(const T* __restrict__ qk
 }
 
 int kv_append(const void* qkv, void* cache, int S, int Lq, int D, long cap, long base, int dtype, hipStream_t st) {
+  ProfScope prof(PROF_TOKENS, 0.0, st);
   const long rows = (long)S * Lq;
   if (rows <= 0) return 0;
   const int V = dtype_is16(dtype) ? 8 : 4;
@@ -681,6 +694,7 @@ __global__ __launch_bounds__(256) void modulate_rows_kernel(const T* __restrict_
 }
 
 int modulate_rows(const void* x, const void* mod, void* out, long rows, int D, int dtype, hipStream_t st) {
+  ProfScope prof(PROF_TOKENS, 0.0, st);
   if (rows <= 0) return 0;
   if (D % 4) return set_error(NOVA_ERR_SHAPE, "modulate_rows: D %% 4 != 0");
   const long total4 = rows * D / 4;

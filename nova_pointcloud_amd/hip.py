@@ -108,7 +108,8 @@ SIGNATURES["nova_debug_drop_graphs"] = []
 SIGNATURES["nova_debug_graph_stats"] = [ctypes.POINTER(c_long), ctypes.POINTER(c_long)]
 SIGNATURES["nova_prof_collect"] = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(ctypes.c_longlong), c_int]
-PROF_SLOTS = ["gemm_bias", "gemm_bias_gelu", "gemm_bias_silu", "qkv_gemm_rope", "attention", "row_norm", "gemm_small_tile"]
+PROF_SLOTS = ["gemm_bias", "gemm_bias_gelu", "gemm_bias_silu", "qkv_gemm_rope", "attention", "row_norm", "gemm_small_tile", "gemm_bias_wide_k",
+              "token_plumbing", "decoder_glue"]
 PLAIN = {"nova_version": (c_int, []), "nova_last_error": (ctypes.c_char_p, []), "nova_check_device": (c_int, [])}
 
 

@@ -172,6 +172,37 @@ def test_attention_spiky_rows(hip, dtype, hd):
 
 
 @pytest.mark.parametrize("dtype", HALF)
+@pytest.mark.parametrize("hd", [64, 96])
+def test_attention_non_finite_rows_stay_in_their_row(hip, dtype, hd):
+    """The contract of nova_attn_fwd for non-finite inputs (include/nova_hip.h; attn16.hip is compiled with -fno-honor-nans, so
+    its max / compare instructions are free to ignore a NaN): a query row whose scores are not all finite - a NaN in the query
+    (query 37), or scores that overflow to +inf (query 150: 1e30 against a key row of 1e30s) - comes out non-finite in ITS
+    output row, as F.scaled_dot_product_attention's would (softmax of a NaN or of inf - inf), and every other output row is
+    bit for bit what the clean input gives: nothing a lane decides wave-wide (the deferred-rescale branch) leaks a row's
+    NaN or inf into its neighbours."""
+    S, heads, L = 2, 2, 333
+    D = heads * hd
+    clean = rnd(S * L, 3 * D, dtype=dtype, seed=21)
+    ref = hip.attn_fwd_packed(clean.clone(), S, L, heads)
+    bad = clean.clone()
+    bad[37, 5] = float("nan")                      # head 0 of sequence 0, query 37
+    bad[150, :hd] = 1e30                           # head 0, query 150 ...
+    bad[200, D:D + hd] = 1e30                      # ... against key 200: the score overflows f32
+    out = hip.attn_fwd_packed(bad, S, L, heads)
+    torch.cuda.synchronize()
+    poisoned = torch.zeros(S * L, D, dtype=torch.bool, device=out.device)
+    poisoned[37, :hd] = True
+    poisoned[150, :hd] = True
+    # key 200 of head 0 is huge for EVERY query of sequence 0, head 0: those rows are dominated by (or overflow on) it - finite or
+    # not, they differ from the clean run by construction; the contract is about all other (sequence, head) pairs and rows
+    touched = torch.zeros_like(poisoned)
+    touched[:L, :hd] = True
+    assert torch.equal(out[~touched], ref[~touched])
+    assert not torch.isfinite(out[37, :hd].float()).any()
+    assert not torch.isfinite(out[150, :hd].float()).any()
+
+
+@pytest.mark.parametrize("dtype", HALF)
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("S,heads,L", [(1, 1, 64), (2, 3, 200), (1, 2, 333), (3, 1, 31), (1, 4, 769), (2, 2, 2560)])
 def test_attention_structures_16bit(hip, dtype, variant, S, heads, L):

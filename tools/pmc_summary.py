@@ -43,22 +43,46 @@ def short(name):
     return m.group(1) + tmpl
 
 
+# One kernel name, two launch shapes: in a ViT block the bias-only 256-tile GEMM is launched twice, out-projection (K = D) then
+# fc2 (K = 4 D), always in that order - the dispatches of such a name are told apart by their position in each pass's dispatch order.
+SPLIT = {"gemm256c_kernel<bf16,0>": ("[proj]", "[fc2]"), "gemm256p_kernel<bf16,0>": ("[proj]", "[fc2]")}
+
+
+def split_by_order(per_pass):
+    """{pass: {kernel: {dispatch: value}}} -> the same with SPLIT names relabelled by dispatch order inside each pass."""
+    out = defaultdict(dict)
+    for k, d in per_pass.items():
+        if k in SPLIT:
+            for i, disp in enumerate(sorted(d)):
+                out[k + SPLIT[k][i % len(SPLIT[k])]][disp] = d[disp]
+        else:
+            out[k] = d
+    return out
+
+
 def counters(root):
     acc = defaultdict(lambda: defaultdict(dict))  # kernel -> counter -> dispatch -> value
     for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+        one = defaultdict(lambda: defaultdict(dict))  # this pass: counter -> kernel -> dispatch -> value
         with open(path) as f:
             for row in csv.DictReader(f):
                 k, c, d = short(row["Kernel_Name"]), row["Counter_Name"], int(row["Dispatch_Id"])
-                acc[k][c][d] = acc[k][c].get(d, 0.0) + float(row["Counter_Value"])
+                one[c][k][d] = one[c][k].get(d, 0.0) + float(row["Counter_Value"])
+        for c, per_kernel in one.items():
+            for k, d in split_by_order(per_kernel).items():
+                acc[k][c].update(d)
     return acc
 
 
 def durations(root):
     out = defaultdict(list)
     for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        one = defaultdict(dict)
         with open(path) as f:
             for row in csv.DictReader(f):
-                out[short(row["Kernel_Name"])].append((int(row["Dispatch_Id"]), (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3))
+                one[short(row["Kernel_Name"])][int(row["Dispatch_Id"])] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+        for k, d in split_by_order(one).items():
+            out[k].extend(sorted(d.items()))
     return out
 
 
@@ -71,9 +95,10 @@ def mean_skip_first(d):
 # algorithmic bytes of one launch at the standard shape (S = 64 x L = 2560 rows, D = 1024, 16 heads, bf16): (operands read, output written)
 ROWS, D_ = 64 * 2560, 1024
 ALGO = {
-    "gemm256p_kernel<bf16,0>": None,  # proj (K = 1024) and fc2 (K = 4096) share this name: reported per launch mix, no single figure
-    "gemm256p_kernel<bf16,1>": (ROWS * D_ * 2 + 4 * D_ * D_ * 2, ROWS * 4 * D_ * 2),          # fc1 + GELU
-    "gemm256p_kernel<bf16,3>": (ROWS * D_ * 2 + 3 * D_ * D_ * 2 + 2560 * 64 * 4, ROWS * 3 * D_ * 2),  # QKV + RoPE (one table)
+    "<bf16,0>[proj]": (ROWS * D_ * 2 + D_ * D_ * 2, ROWS * D_ * 2),                # out-projection
+    "<bf16,0>[fc2]": (ROWS * 4 * D_ * 2 + 4 * D_ * D_ * 2, ROWS * D_ * 2),         # fc2
+    "<bf16,1>": (ROWS * D_ * 2 + 4 * D_ * D_ * 2, ROWS * 4 * D_ * 2),              # fc1 + GELU
+    "<bf16,3>": (ROWS * D_ * 2 + 3 * D_ * D_ * 2 + 2560 * 64 * 4, ROWS * 3 * D_ * 2),  # QKV + RoPE (one table)
     "attn": (ROWS * 3 * D_ * 2, ROWS * D_ * 2),
     "row_norm": (2 * ROWS * D_ * 2, ROWS * D_ * 2),
 }
@@ -84,6 +109,8 @@ def algo_for(k):
         return ALGO.get("attn")
     if k.startswith("row_norm"):
         return ALGO.get("row_norm")
+    if k.startswith("gemm256"):  # either persistent form
+        return ALGO.get(k[k.index("<"):])
     return ALGO.get(k)
 
 
@@ -95,6 +122,7 @@ def main():
         shape = args[i + 1]
         del args[i:i + 2]
         ALGO.clear()
+        SPLIT.clear()
     sys.argv = [sys.argv[0]] + args
     root, out_path = sys.argv[1], sys.argv[2]
     acc, dur = counters(root), durations(root)
