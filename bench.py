@@ -129,10 +129,10 @@ def cpu_baseline(pipe, width, heads, H, W, threads, with_config0=False):
 
 
 # kernel names (tools/pmc_summary.py's short form) behind each timed family, in the bf16 run and in the fp8 GEMM mode
-PMC_KERNEL_FP8 = {"attention": "attn_bf16_m16<bf16,96,2,false,true,false>", "gemm_bias": "gemm256c_kernel<bf16,0>", "gemm_bias_wide_k": "gemm256p_kernel<fp8,0>",
+PMC_KERNEL_FP8 = {"attention": "attn_bf16_m16<bf16,96,2,false,true,false>", "gemm_bias": "gemm256c_kernel<bf16,0,false>", "gemm_bias_wide_k": "gemm256p_kernel<fp8,0>",
                   "gemm_bias_gelu": "gemm256p_kernel<fp8,5>", "qkv_gemm_rope": "gemm256p_kernel<fp8,3>"}
-PMC_KERNEL = {"attention": "attn_bf16_m16<bf16,64,2,false,true,false>", "gemm_bias": "gemm256c_kernel<bf16,0>[proj]", "gemm_bias_wide_k": "gemm256c_kernel<bf16,0>[fc2]",
-              "gemm_bias_gelu": "gemm256c_kernel<bf16,1>", "qkv_gemm_rope": "gemm256c_kernel<bf16,3>"}
+PMC_KERNEL = {"attention": "attn_bf16_m16<bf16,64,2,false,true,false>", "gemm_bias": "gemm256c_kernel<bf16,0,false>[proj]", "gemm_bias_wide_k": "gemm256c_kernel<bf16,0,false>[fc2]",
+              "gemm_bias_gelu": "gemm256c_kernel<bf16,1,false>", "qkv_gemm_rope": "gemm256c_kernel<bf16,3,true>"}
 MFMA_FAMILIES = ("attention", "qkv_gemm_rope", "gemm_bias", "gemm_bias_wide_k", "gemm_bias_gelu", "gemm_bias_silu", "gemm_small_tile")
 
 

@@ -45,7 +45,7 @@ def short(name):
 
 # One kernel name, two launch shapes: in a ViT block the bias-only 256-tile GEMM is launched twice, out-projection (K = D) then
 # fc2 (K = 4 D), always in that order - the dispatches of such a name are told apart by their position in each pass's dispatch order.
-SPLIT = {"gemm256c_kernel<bf16,0>": ("[proj]", "[fc2]"), "gemm256p_kernel<bf16,0>": ("[proj]", "[fc2]")}
+SPLIT = {"gemm256c_kernel<bf16,0,false>": ("[proj]", "[fc2]"), "gemm256p_kernel<bf16,0>": ("[proj]", "[fc2]")}
 
 
 def split_by_order(per_pass):
@@ -95,10 +95,10 @@ def mean_skip_first(d):
 # algorithmic bytes of one launch at the standard shape (S = 64 x L = 2560 rows, D = 1024, 16 heads, bf16): (operands read, output written)
 ROWS, D_ = 64 * 2560, 1024
 ALGO = {
-    "<bf16,0>[proj]": (ROWS * D_ * 2 + D_ * D_ * 2, ROWS * D_ * 2),                # out-projection
-    "<bf16,0>[fc2]": (ROWS * 4 * D_ * 2 + 4 * D_ * D_ * 2, ROWS * D_ * 2),         # fc2
-    "<bf16,1>": (ROWS * D_ * 2 + 4 * D_ * D_ * 2, ROWS * 4 * D_ * 2),              # fc1 + GELU
-    "<bf16,3>": (ROWS * D_ * 2 + 3 * D_ * D_ * 2 + 2560 * 64 * 4, ROWS * 3 * D_ * 2),  # QKV + RoPE (one table)
+    "0[proj]": (ROWS * D_ * 2 + D_ * D_ * 2, ROWS * D_ * 2),                # out-projection
+    "0[fc2]": (ROWS * 4 * D_ * 2 + 4 * D_ * D_ * 2, ROWS * D_ * 2),         # fc2
+    "1": (ROWS * D_ * 2 + 4 * D_ * D_ * 2, ROWS * 4 * D_ * 2),              # fc1 + GELU
+    "3": (ROWS * D_ * 2 + 3 * D_ * D_ * 2 + 2560 * 64 * 4, ROWS * 3 * D_ * 2),  # QKV + RoPE (one table)
     "attn": (ROWS * 3 * D_ * 2, ROWS * D_ * 2),
     "row_norm": (2 * ROWS * D_ * 2, ROWS * D_ * 2),
 }
@@ -109,8 +109,9 @@ def algo_for(k):
         return ALGO.get("attn")
     if k.startswith("row_norm"):
         return ALGO.get("row_norm")
-    if k.startswith("gemm256"):  # either persistent form
-        return ALGO.get(k[k.index("<"):])
+    if k.startswith("gemm256"):  # either persistent form: <bf16,EPI[,table-through-LDS]>[label]
+        m = re.match(r"gemm256[cp]_kernel<bf16,(\d)(?:,\w+)?>(\[\w+\])?", k)
+        return ALGO.get(m.group(1) + (m.group(2) or "")) if m else None
     return ALGO.get(k)
 
 
