@@ -110,7 +110,7 @@ int nova_check_device(void) {
 
 int nova_debug_force_gemm_tile(int tile) {
   NOVA_REQUIRE(gemm_force_tile(tile) == 0, NOVA_ERR_ARG,
-               "force_gemm_tile: this build knows 0 (auto), 16 (small-M kernel; 161 / 162 / 164 with 16 / 32 / 64 rows per workgroup), 128, 256 (persistent), 257 (one tile per workgroup) and 258 (persistent, prologue form); experiment codes need the NOVA_EXPERIMENTS build");
+               "force_gemm_tile: this build knows 0 (auto), 16 (small-M kernel; 161 / 162 / 164 with 16 / 32 / 64 rows per workgroup), 64 / 128 (the small-M tile kernels), 256 (persistent), 257 (one tile per workgroup) and 258 (persistent, prologue form); experiment codes need the NOVA_EXPERIMENTS build");
   return 0;
 }
 

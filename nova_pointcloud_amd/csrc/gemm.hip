@@ -20,9 +20,7 @@
 
 namespace nova {
 
-constexpr int BM = 128, BN = 128, ROWB = 128;       // ROWB: bytes of K per tile row
-constexpr int TILE_BYTES = BM * ROWB;               // 16 KiB per operand tile
-constexpr int GEMM_LDS = 4 * TILE_BYTES;            // A,W x 2 buffers = 64 KiB
+constexpr int ROWB = 128;       // bytes of K per tile row
 
 struct GemmEpi {
   const float* bias;     // [N] or nullptr
@@ -60,11 +58,15 @@ __device__ __forceinline__ Frag<T> lds_frag(const char* tile, int row, int chunk
   return f;
 }
 
-template <typename T, int EPI>
+// F = MFMA fragments per wave and dimension: 4 -> the 128x128 tile described above; 2 -> a 64x64 tile (round 4) for the denoising
+// loop's launches at 1100 .. 4000 rows, where the 128 tile gives fewer workgroups than CUs and a workgroup's LDS-DMA rate, not the chip's,
+// sets the time: a quarter of the operand bytes per workgroup, four times the workgroups. Same MFMA, same k order: bit-identical.
+template <typename T, int EPI, int F = 4>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                        T* __restrict__ C, int M, int N, int K, int ntm,
                                                        int ntn, GemmEpi e) {
-  __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+  constexpr int BM = 32 * F, BN = 32 * F, TILE_BYTES = BM * ROWB, WT = 16 * F;  // tile, bytes of one operand tile, rows / columns per wave
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
 
@@ -79,24 +81,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
   const int tn = (t % per_group) / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- staging addresses: wave w owns LDS-DMA pieces 4w..4w+3 (8 rows x 128 B each) of A and W
+  // ---- staging addresses: wave w owns LDS-DMA pieces F w .. F w + F - 1 (8 rows x 128 B each) of A and W
   const int rr = lane >> 3, cp = lane & 7;
-  const char* a_src[4];
-  const char* w_src[4];
+  const char* a_src[4];  // (F used; sized by the constant: an array sized by the template parameter and captured by the lambda
+  const char* w_src[4];  //  below makes hipcc drop the kernel's host stub - no diagnostic, an undefined symbol at load time)
   const size_t rowbytes = (size_t)K * sizeof(T);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wid * 4 + i) * 8 + rr;                 // row inside the tile
+  for (int i = 0; i < F; ++i) {
+    const int row = (wid * F + i) * 8 + rr;                 // row inside the tile
     const int c = cp ^ ((row >> 1) & 7);                    // logical 16-B chunk this lane fetches
     const int am = min(m0 + row, M - 1);                    // clamp: rows past M are never stored
     a_src[i] = reinterpret_cast<const char*>(A) + (size_t)am * rowbytes + c * 16;
     w_src[i] = reinterpret_cast<const char*>(W) + (size_t)(n0 + row) * rowbytes + c * 16;
   }
   auto stage = [&](int buf, int kt) {
-    char* la = smem + buf * 2 * TILE_BYTES + wid * 4096;
+    char* la = smem + buf * 2 * TILE_BYTES + wid * F * 1024;
     char* lw = la + TILE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < F; ++i) {
       __builtin_amdgcn_global_load_lds(a_src[i] + (size_t)kt * ROWB, NOVA_LDS_PTR(la + i * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds(w_src[i] + (size_t)kt * ROWB, NOVA_LDS_PTR(lw + i * 1024), 16, 0, 0);
     }
@@ -107,18 +109,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 
   // The accumulators START at the bias (all three GEMM kernels do, so that they stay bit-identical): no add in the
   // epilogue, where every VALU issue is paid with the matrix pipe idle.
-  f4v bv[4];
+  f4v bv[F];
 #pragma unroll
-  for (int nf = 0; nf < 4; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
+  for (int nf = 0; nf < F; ++nf) bv[nf] = f4v{0.f, 0.f, 0.f, 0.f};
   if (e.bias) {
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wn * 64 + nf * 16 + fg * 4);
+    for (int nf = 0; nf < F; ++nf) bv[nf] = *reinterpret_cast<const f4v*>(e.bias + n0 + wn * WT + nf * 16 + fg * 4);
   }
-  f4v acc[4][4];  // [nf][mf]
+  f4v acc[F][F];  // [nf][mf]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < F; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = bv[i];
+    for (int j = 0; j < F; ++j) acc[i][j] = bv[i];
 
   stage(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
@@ -132,16 +134,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
     const char* tw = ta + TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      Frag<T> af[4], wf[4];
+      Frag<T> af[F], wf[F];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        af[f] = lds_frag<T>(ta, wm * 64 + f * 16 + fr, fg + 4 * kk);
-        wf[f] = lds_frag<T>(tw, wn * 64 + f * 16 + fr, fg + 4 * kk);
+      for (int f = 0; f < F; ++f) {
+        af[f] = lds_frag<T>(ta, wm * WT + f * 16 + fr, fg + 4 * kk);
+        wf[f] = lds_frag<T>(tw, wn * WT + f * 16 + fr, fg + 4 * kk);
       }
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf)
+      for (int nf = 0; nf < F; ++nf)
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) acc[nf][mf] = mma(wf[nf], af[mf], acc[nf][mf]);
+        for (int mf = 0; mf < F; ++mf) acc[nf][mf] = mma(wf[nf], af[mf], acc[nf][mf]);
     }
   }
 
@@ -150,19 +152,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
   // overlap instead of serialising behind per-fragment branches.
   const bool rot = EPI == EPI_ROPE && n0 < e.rope_cols;  // tile-uniform: rope_cols is a multiple of the tile width
 #pragma unroll
-  for (int mf = 0; mf < 4; ++mf) {
-    const int m = m0 + wm * 64 + mf * 16 + fr;
+  for (int mf = 0; mf < F; ++mf) {
+    const int m = m0 + wm * WT + mf * 16 + fr;
     if (m >= M) continue;
-    f4v cs[4];
+    f4v cs[F];
     if (rot) {
       const int s = m / e.L, l = m - s * e.L;
       const float* ropem = e.rope + ((size_t)(s % e.rope_batch) * e.L + l) * e.hd;  // hd/2 pairs x (cos, sin)
 #pragma unroll
-      for (int nf = 0; nf < 4; ++nf) cs[nf] = *reinterpret_cast<const f4v*>(ropem + (n0 + wn * 64 + nf * 16 + fg * 4) % e.hd);
+      for (int nf = 0; nf < F; ++nf) cs[nf] = *reinterpret_cast<const f4v*>(ropem + (n0 + wn * WT + nf * 16 + fg * 4) % e.hd);
     }
-    T* dst = C + (size_t)m * N + n0 + wn * 64 + fg * 4;
+    T* dst = C + (size_t)m * N + n0 + wn * WT + fg * 4;
 #pragma unroll
-    for (int nf = 0; nf < 4; ++nf) {
+    for (int nf = 0; nf < F; ++nf) {
       f4v v = acc[nf][mf];
       if (EPI == EPI_GELU) {
 #pragma unroll
@@ -233,7 +235,7 @@ int gemm_force_tile(int tile) {
   } else {
     skinny_force_row_blocks(0);
   }
-  if (tile != 0 && tile != 16 && tile != 128 && tile != 256 && tile != 257 && tile != 258) return -1;
+  if (tile != 0 && tile != 16 && tile != 64 && tile != 128 && tile != 256 && tile != 257 && tile != 258) return -1;
   g_force_tile = tile;  // 257: the 256 tile in its one-tile-per-workgroup form; 258: its persistent prologue form (256: the shipped choice);
   return 0;             // 16: the small-M kernel of skinny.hip wherever its shapes allow (an error elsewhere)
 }
@@ -253,7 +255,7 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
                        hipStream_t st) {
   const int kelems = ROWB / (int)sizeof(T);
   if (M <= 0) return 0;
-  if (N % BN != 0 || K % kelems != 0 || K <= 0)
+  if (N % 128 != 0 || K % kelems != 0 || K <= 0)
     return set_error(NOVA_ERR_SHAPE, "gemm: need N %% 128 == 0 and K %% %d == 0 (got M=%d N=%d K=%d)", kelems, M, N, K);
   const bool can256 = N % 256 == 0 && (epi != EPI_ROPE || (e.rope_cols % 256 == 0 && e.q_cols % 256 == 0));  // rotation is decided per tile
   if (g_force_tile >= 256 && !can256) return set_error(NOVA_ERR_SHAPE, "gemm: 256-tile kernel needs N %% 256 == 0");
@@ -265,12 +267,33 @@ static int launch_gemm(const void* A, const void* W, void* C, int M, int N, int 
   if (can256 && (g_force_tile >= 256 || (g_force_tile == 0 && M >= 4096 && tiles256 >= min_tiles256())))
     return gemm256_launch(A, W, C, M, N, K, epi, e.bias, e.rope, e.L, e.rope_batch, e.hd, e.rope_cols, e.q_scale, e.q_cols,
                           dtype_of<T>(), st, g_force_tile == 257 ? 1 : g_force_tile == 258 ? 2 : 0);
-  const int ntm = (M + BM - 1) / BM, ntn = N / BN;
-  dim3 grid(ntm * ntn), block(256);
+  constexpr int BM = 128, BN = 128;
+  int ntm = (M + BM - 1) / BM, ntn = N / BN;
   ProfScope prof(PROF_GEMM_SMALL, 2.0 * M * N * K, st);
   const T* a = static_cast<const T*>(A);
   const T* w = static_cast<const T*>(W);
   T* c = static_cast<T*>(C);
+  // fewer 128 x 128 tiles than CUs (the denoising loop at 1100 .. 4000 rows): 64 x 64 tiles - the launch is bound by what ONE workgroup
+  // can pull through its CU, so four times the workgroups at a quarter of the operand bytes each (rotated tiles stay on the 128 tile:
+  // the 64 tile's columns would split a head's table row differently only in cost, not in result, but it is not needed there).
+  // NOVA_GEMM_TILE64=0 keeps the 128 tile (A/B: tools/gemm_tile64_ab.py)
+  static const bool tile64_ok = [] { const char* v = getenv("NOVA_GEMM_TILE64"); return !(v && v[0] == '0'); }();
+  // (3/4 of the CUs: at 208 tiles of 128 and more the 64 tile is 3-4 % behind, at 192 it is 1.1-1.2 x ahead, at 128 tiles 1.4 x:
+  // profiles/r04_gemm_tile64_ab.txt, r04_gemm_small_m_tiles.txt)
+  if (g_force_tile == 64 || (tile64_ok && g_force_tile == 0 && epi != EPI_ROPE && (long)ntm * ntn * 4 <= (long)gemm256_cu_count() * 3)) {
+    if (epi == EPI_ROPE) return set_error(NOVA_ERR_SHAPE, "gemm: the 64 tile has no RoPE epilogue");
+    ntm = (M + 63) / 64;
+    ntn = N / 64;
+    dim3 grid64(ntm * ntn), block(256);
+    switch (epi) {
+      case EPI_NONE: hipLaunchKernelGGL((gemm_kernel<T, EPI_NONE, 2>), grid64, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+      case EPI_GELU: hipLaunchKernelGGL((gemm_kernel<T, EPI_GELU, 2>), grid64, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+      case EPI_SILU: hipLaunchKernelGGL((gemm_kernel<T, EPI_SILU, 2>), grid64, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
+      default: return set_error(NOVA_ERR_ARG, "gemm: unknown epilogue %d", epi);
+    }
+    return check_launch("gemm (64 tile)");
+  }
+  dim3 grid(ntm * ntn), block(256);
   switch (epi) {
     case EPI_NONE: hipLaunchKernelGGL((gemm_kernel<T, EPI_NONE>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;
     case EPI_GELU: hipLaunchKernelGGL((gemm_kernel<T, EPI_GELU>), grid, block, 0, st, a, w, c, M, N, K, ntm, ntn, e); break;

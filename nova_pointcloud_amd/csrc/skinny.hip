@@ -146,22 +146,33 @@ static void launch_skinny_k(const T* a, const T* w, T* c, int M, int N, const fl
 // or 4 row blocks) until the 128-tile kernel's LDS-shared operands win. Kernel durations under rocprofv3, N = K = D
 // (tools/skinny_bench.py; us at D = 768 | 1024, 128-tile kernel 11-12 | 13-15 throughout):
 //   M <= 256: 16 rows 5.7-5.9 | 6.3-7.3      M 400-512: 32 rows 7.0-7.2 | 8.8      M 800-1024: 64 rows 9.2 | 12.2
-//   M >= 1600: none (14-37 | 21-46).   Modulate + fc1 in one launch (16 rows only): 9.4-9.7 | 10.4-11.7 up to M = 256
+//   M >= 1600: none (14-37 | 21-46).   [round 4: superseded for the plain GEMM by the rule in skinny_row_blocks]   Modulate + fc1 in one launch (16 rows only): 9.4-9.7 | 10.4-11.7 up to M = 256
 //   against 14.4-15.1 | 18.1-18.3 for row_norm + GEMM; from M = 400 on the two launches are faster.
 // skinny_row_blocks returns 1, 2, 4 (x 16 rows) or 0 = use the tile kernels.
 static thread_local int g_skinny_rb = 0;  // tools / tests: force a row-block count (0 = by the rule above)
 void skinny_force_row_blocks(int rb) { g_skinny_rb = rb; }
 int skinny_forced_row_blocks() { return g_skinny_rb; }
 
+int gemm256_cu_count();  // gemm256.hip: CUs of the device
+
 int skinny_row_blocks(int M, int N, int K, bool modulate) {
   if (M <= 0 || (K != 768 && K != 1024) || N % SK_C != 0) return 0;
   if (g_skinny_rb == 1 || g_skinny_rb == 2 || g_skinny_rb == 4) return modulate ? 1 : g_skinny_rb;
-  const int rb = M <= 320 ? 1 : (modulate ? 0 : M <= 640 ? 2 : M <= 1100 ? 4 : 0);
-  if (rb == 0) return 0;
-  // wide outputs (N >> K: the AdaLN projection, fc1 of a ViT block): the weight re-reads of all row tiles must stay a few
-  // tens of MB of L2 traffic, or the tile kernels' once-per-128-rows weight reads win
-  const double weight_bytes = (double)((M + SK_R * rb - 1) / (SK_R * rb)) * N * K * 2.0;
-  return weight_bytes <= 64.0e6 ? rb : 0;
+  const bool tiles_can = N % 128 == 0;  // the 64 x 64 tile kernel of gemm.hip takes the shape
+  if (modulate || !tiles_can) {
+    const int rb = M <= 320 ? 1 : (modulate ? 0 : M <= 640 ? 2 : M <= 1100 ? 4 : 0);
+    if (rb == 0) return 0;
+    // wide outputs (N >> K: the AdaLN projection, fc1 of a ViT block): the weight re-reads of all row tiles must stay a few
+    // tens of MB of L2 traffic, or the tile kernels' once-per-tile-row weight reads win
+    const double weight_bytes = (double)((M + SK_R * rb - 1) / (SK_R * rb)) * N * K * 2.0;
+    return weight_bytes <= 64.0e6 ? rb : 0;
+  }
+  // Plain GEMM, round 4: the 64 x 64 tile kernel is level with the 16-row form while this kernel's workgroups all fit the chip at once
+  // and ahead of it beyond (N = K = 1024: 9.3 against 10.8 us at M = 512, 10.3 against 13.7 at 1024; N = 3072: 9.4 against 12.2 us at
+  // M = 96, where 288 workgroups need a second round: profiles/r04_gemm_small_m_tiles.txt), so the 32- and 64-row forms are only
+  // reached through the force codes now.
+  const long wgs = (long)((M + SK_R - 1) / SK_R) * (N / SK_C);
+  return wgs <= gemm256_cu_count() ? 1 : 0;
 }
 
 bool skinny_gemm_fits(int M, int N, int K, bool modulate) { return skinny_row_blocks(M, N, K, modulate) != 0; }

@@ -395,6 +395,29 @@ def test_small_m_gemm_bitwise_equals_tile_kernels(hip, force_tile, dtype, M, N, 
     assert torch.equal(out, hip.gemm_bias_act(a, w, bias, act))
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1, 128, 64, 0), (63, 256, 128, 1), (64, 1024, 1024, 2), (65, 768, 768, 0), (400, 1536, 1536, 2), (1152, 1024, 1024, 0),
+                                        (1632, 1024, 1024, 2), (1000, 3072, 1024, 0), (2047, 1536, 1536, 1), (3264, 1024, 1024, 0), (517, 1024, 4096, 0)])
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_64_tile_bitwise_equals_128_tile(hip, force_tile, dtype, M, N, K, act):
+    """gemm.hip's 64 x 64 tile (the launches of the denoising loop, where 128 x 128 tiles would leave CUs idle: forced here, chosen by
+    tile count otherwise) against the 128 x 128 tile, bit for bit, with and without bias, ragged last row tile included; the automatic
+    choice between the small-M kernel, the 64 tile and the 128 tile gives the same bits again."""
+    a, w = rnd(M, K, dtype=dtype, seed=57), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=58)
+    bias = rnd(N, seed=59)
+    force_tile(128)
+    ref, ref_nb = hip.gemm_bias_act(a, w, bias, act), hip.gemm_bias_act(a, w, None, act)
+    force_tile(64)
+    pad = torch.full((M + 2, N), 7.0, dtype=dtype, device="cuda")   # rows beyond M stay untouched
+    out = hip.gemm_bias_act(a, w, bias, act, out=pad[:M])
+    assert torch.equal(out, ref) and torch.equal(hip.gemm_bias_act(a, w, None, act), ref_nb)
+    assert bool((pad[M:] == 7.0).all())
+    force_tile(0)
+    assert torch.equal(hip.gemm_bias_act(a, w, bias, act), ref)
+    full = a.float() @ w.float().T + bias
+    full = [lambda x: x, torch.nn.functional.gelu, torch.nn.functional.silu][act](full)
+    assert relerr(out, full) < tol(dtype)
+
+
 def test_small_m_gemm_rejects_other_shapes(hip, force_tile):
     force_tile(16)
     a, w = rnd(32, 512, dtype=torch.bfloat16), rnd(128, 512, dtype=torch.bfloat16)
