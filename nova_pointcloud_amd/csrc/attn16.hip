@@ -64,6 +64,11 @@ __device__ __forceinline__ float sum_over_g(float x) {
 // of frames <= its own; the prefix counts as frame 0). Tiles are then walked in natural order (tile 0 holds an allowed key for
 // every row, so the first step's max is finite), every tile applies the limit, and tiles past the workgroup's largest limit are
 // never staged.
+#ifdef NOVA_CLOCK
+// Diagnostic build only (tools/kernel_clock.py): shader cycles and 100 MHz ticks between a workgroup's start and end, kept for the
+// last workgroup that used each of 1024 slots (MI355X_MICROARCH.md, 'DVFS give-back' item 6)
+__device__ long long g_attn_clock[2 * 1024];
+#endif
 template <typename E, int HD, int NQB, bool LSE, bool SUMM, bool MASK = false>  // E: bf16_t / f16_t (same loads, LDS images and stores; MFMA form and pair packing differ)
 __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16_m16(const E* __restrict__ q, const E* __restrict__ k,
                                                                          const E* __restrict__ v, E* __restrict__ o,
@@ -75,6 +80,9 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
   constexpr int BUF = 2 * B_T + (HD == 96 ? 2 * B_T32 : 0);         // [K64 | V64 | K32 | V32]
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef NOVA_CLOCK
+  const long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int t = xcd_remap_dir(blockIdx.x, gridDim.x, rev != 0);
@@ -301,6 +309,9 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
     if (j + 1 < nkt) stage((j + 1) & 1, tile_of(j + 1));
     step(std::false_type{}, j & 1, tile_of(j));
   }
+  // (Skipping the steps of a wave whose query rows all lie past Lq - `if (q0 < Lq) step(...)`, wave-uniform - was measured and lost at
+  // every length, 2 % at L = 2560 where no wave is idle and 24 % at L = 768: the guarded call changes the loop hipcc builds.
+  // profiles/r04_attn_dead_wave_skip_rejected.txt)
 
   // ---- finalize: lane (i, g) holds O[q0 + 16 qb + i][16 dvb + 4 g + 0..3]
 #pragma unroll
@@ -318,6 +329,12 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
       }
     }
   }
+#ifdef NOVA_CLOCK
+  if (tid == 0) {
+    g_attn_clock[2 * (blockIdx.x & 1023)] = __builtin_amdgcn_s_memtime() - ck_t0;
+    g_attn_clock[2 * (blockIdx.x & 1023) + 1] = __builtin_amdgcn_s_memrealtime() - ck_r0;
+  }
+#endif
 }
 
 
@@ -337,6 +354,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const E* __restrict__ q
   constexpr int NQB = 4, HD = 64, NDS = 2, NDVB = 4, RW = 64;
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * B_T + 4 * 64 * 128];  // [buffer][K | V], then the waves' Q rows
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef NOVA_CLOCK
+  const long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int t = xcd_remap_dir(blockIdx.x, gridDim.x, rev != 0);
@@ -571,7 +591,21 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_m16p(const E* __restrict__ q
       }
     }
   }
+#ifdef NOVA_CLOCK
+  if (tid == 0) {
+    g_attn_clock[2 * (blockIdx.x & 1023)] = __builtin_amdgcn_s_memtime() - ck_t0;
+    g_attn_clock[2 * (blockIdx.x & 1023) + 1] = __builtin_amdgcn_s_memrealtime() - ck_r0;
+  }
+#endif
 }
+
+#ifdef NOVA_CLOCK
+}  // namespace nova
+extern "C" int nova_debug_attn_clock(long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nova::g_attn_clock), (size_t)(n < 2048 ? n : 2048) * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+namespace nova {
+#endif
 
 // rows_per_wave 32 or 64 (head_dim 64; head_dim 96 runs the 32-row form with MFMA row sums whatever is asked); dtype NOVA_BF16 or NOVA_F16 (attn_fwd in attn.hip checks shapes and strides before it dispatches here)
 int attn_fwd_m16(const void* q, const void* k, const void* v, void* o, int S, int heads, int Lq, int Lk, int hd, long q_rs, long kv_rs,

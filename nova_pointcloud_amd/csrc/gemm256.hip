@@ -154,7 +154,15 @@ __device__ __forceinline__ void store4(OT* dst, f4v v) {  // 4 consecutive colum
 template <typename OT>
 __device__ __forceinline__ void store8(OT* dst, f4v lo, f4v hi) {  // 8 consecutive columns of one row
   if constexpr (sizeof(OT) == 2) {
-    *reinterpret_cast<u4v*>(dst) = u4v{Half16<OT>::pack(lo[0], lo[1]), Half16<OT>::pack(lo[2], lo[3]), Half16<OT>::pack(hi[0], hi[1]), Half16<OT>::pack(hi[2], hi[3])};
+    const u4v pk = u4v{Half16<OT>::pack(lo[0], lo[1]), Half16<OT>::pack(lo[2], lo[3]), Half16<OT>::pack(hi[0], hi[1]), Half16<OT>::pack(hi[2], hi[3])};
+    // Streaming (`nt`) stores: a round of an XCD's 32 workgroups writes 4 MB of output through a 4 MB L2 that the same round's operand
+    // panels are being re-read from; marked streaming the output lines go first. 1.4-2.3 % on the K = 1024 launches, level at K = 4096,
+    // the LayerNorm pass that reads the result next is not slower (profiles/r04_gemm_nt_stores_ab.txt; -DNOVA_PLAIN_STORES: the A/B build)
+#ifdef NOVA_PLAIN_STORES
+    *reinterpret_cast<u4v*>(dst) = pk;
+#else
+    __builtin_nontemporal_store(pk, reinterpret_cast<u4v*>(dst));
+#endif
   } else {
     *reinterpret_cast<f4v*>(dst) = lo;
     *reinterpret_cast<f4v*>(dst + 4) = hi;
@@ -366,6 +374,13 @@ constexpr int P_STAMPS = 2 * STAMP_TILES * STAMP_PTS * 4;
 #else
 #define NOVA_STAMP(k) do {} while (0)
 constexpr int P_STAMPS = 0;
+#endif
+
+#ifdef NOVA_CLOCK
+// Diagnostic build only (tools/kernel_clock.py): every workgroup of the continuous form reads the shader clock (s_memtime) and the
+// constant 100 MHz clock (s_memrealtime) once when it starts and once when it ends: the quotient is the clock the chip held
+// under this kernel's load (MI355X_MICROARCH.md, 'DVFS give-back' item 6). No stamp inside the loop.
+__device__ long long g_gemm_clock[2 * 1024];
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -747,6 +762,9 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
   const int csize = cq + (xcd < cr ? 1 : 0);
   if (slot >= csize) return;  // workgroup-uniform, before any barrier
 
+#ifdef NOVA_CLOCK
+  const long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int GM = e.gm;
   const int per_group = GM * ntn;
   auto tile_origin = [&](int t, int& m0, int& n0) {
@@ -770,6 +788,7 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
   auto stage = [&](int u, int kt) {  // unit u of K-tile kt of the staged tile
     char* dst = smem + (kt & 1) * P_BUF + unit_off(u) + wid * 2048;
     const char* base = ((u == 0 || u == 2) ? w_base : a_base) + (size_t)kt * 128;
+    // (the `nt` policy on either operand's staging loads loses 3-10 %: profiles/r04_gemm_nt_stores_ab.txt)
     __builtin_amdgcn_global_load_lds(base + soff[u][0], NOVA_LDS_PTR(dst), 16, 0, 0);
     __builtin_amdgcn_global_load_lds(base + soff[u][1], NOVA_LDS_PTR(dst + 1024), 16, 0, 0);
   };
@@ -1063,6 +1082,12 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
     m0 = nm0;
     n0 = nn0;
   }
+#ifdef NOVA_CLOCK
+  if (tid == 0 && blockIdx.x < 1024) {
+    g_gemm_clock[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - ck_t0;
+    g_gemm_clock[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - ck_r0;
+  }
+#endif
 #ifdef NOVA_STAMPS
   if (!TDMA && blockIdx.x == 0) {
     __syncthreads();
@@ -1071,6 +1096,13 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
 #endif
 }
 
+#ifdef NOVA_CLOCK
+}  // namespace nova
+extern "C" int nova_debug_gemm_clock(long long* out, int n) {  // diagnostic build only: (shader cycles, 100 MHz ticks) per workgroup of the last launch
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nova::g_gemm_clock), (size_t)(n < 2048 ? n : 2048) * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+namespace nova {
+#endif
 #ifdef NOVA_STAMPS
 }  // namespace nova
 extern "C" int nova_debug_gemm_stamps(unsigned* out, int n) {  // diagnostic build only: the record of the last persistent launch

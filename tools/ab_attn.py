@@ -19,7 +19,7 @@ for path in sys.argv[1:]:
 dt = torch.bfloat16
 st = torch.cuda.current_stream().cuda_stream
 g = torch.Generator().manual_seed(0)
-for (S, heads, hd, L) in [(64, 16, 64, 2560), (64, 16, 64, 1537), (64, 16, 96, 2560)]:
+for (S, heads, hd, L) in [(64, 16, 64, 2560), (64, 16, 64, 768), (64, 16, 64, 1280), (64, 16, 64, 1537), (64, 16, 64, 2049), (64, 16, 64, 2510), (64, 16, 96, 2560), (64, 16, 96, 1537)]:
     D = heads * hd
     qkv = torch.randn(S * L, 3 * D, generator=g)
     qkv[:, :D] *= hd ** -0.5 * 1.4426950408889634  # what the fused QKV epilogue delivers
