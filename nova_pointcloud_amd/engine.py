@@ -222,8 +222,8 @@ class NovaEngine(object):
         lpk.n2 = (lpk.f(lb.norm2.weight), lpk.f(lb.norm2.bias))
         self.dec = pack_decoder(de, dtype)
         pk = self.misc = _Pack()
-        te = m.text_embed
-        self.text = (pk.w(te.proj.weight, dtype), pk.f(te.proj.bias), pk.f(te.norm.weight), pk.f(te.norm.bias))
+        te = m.text_embed  # None: a model conditioned through pre-supplied rows only (inputs["c"], transformer_3d.py:66)
+        self.text = None if te is None else (pk.w(te.proj.weight, dtype), pk.f(te.proj.bias), pk.f(te.norm.weight), pk.f(te.norm.bias))
         self.vnorm = (pk.f(ve.norm.weight), pk.f(ve.norm.bias))
         self.inorm = (pk.f(ie.norm.weight), pk.f(ie.norm.bias))
         self.patch = (pk.w(patch_weight(ie.patch_embed.proj), dtype), pk.f(ie.patch_embed.proj.bias))
@@ -408,19 +408,29 @@ class NovaEngine(object):
         if scaler.image_guidance_scale and scaler.spatiotemporal_guidance_scale:
             raise ValueError("image_guidance_scale and spatiotemporal_guidance_scale are exclusive (the reference's expand_text "
                              "builds four text blocks for three guidance passes when both are set, guidance_scaler.py:46-57)")
-        if m.text_embed is None:
-            raise NotImplementedError("label-conditioned models (text_embed = None) are not built on the HIP path")
-        if inputs.get("c", None):
-            raise NotImplementedError("a pre-supplied condition list inputs['c'] is not built on the HIP path")
+        # Condition rows (transformer_3d.py:63-77): the caller's own list inputs["c"] (model-width rows [S0, Lc_i, D], e.g. label
+        # embeddings), then TextEmbed(prompt) when the model has a text embedding and a prompt is given, then the motion tokens -
+        # concatenated along the token axis in that order.
+        pre = [t for t in (inputs.get("c", None) or [])]
+        prompt = inputs.get("prompt", None)
+        use_text = prompt is not None and m.text_embed is not None
+        if not use_text and not pre:
+            raise ValueError("no condition rows: give a prompt (model with a text embedding) or a list of rows inputs['c']")
         T = int(inputs.get("max_latent_length", 1))
         ie, ve = m.image_encoder, m.video_encoder
         C, (H, W), p = ie.image_dim, ie.image_size, ie.patch_embed.patch_size
         h, w = H // p, W // p
         N, P = h * w, p * p * C
-        prompt = inputs["prompt"]
-        if isinstance(prompt, (tuple, list)):  # strings or per-prompt embeddings: host-side padding (embeddings.py:179-201)
+        if not use_text:
+            prompt = None
+        elif isinstance(prompt, (tuple, list)):  # strings or per-prompt embeddings: host-side padding (embeddings.py:179-201)
             prompt = m.text_embed.encode_prompts(prompt)
-        S0 = prompt.shape[0]
+        pre_c = None
+        if pre:
+            pre_c = (torch.cat(pre, dim=1) if len(pre) > 1 else pre[0]).to(device=dev, dtype=dtype)
+            if pre_c.dim() != 3 or pre_c.shape[-1] != self.D or (prompt is not None and pre_c.shape[0] != prompt.shape[0]):
+                raise ValueError(f"inputs['c'] rows {tuple(pre_c.shape)} do not fit: want [{'S' if prompt is None else prompt.shape[0]}, Lc, {self.D}]")
+        S0 = prompt.shape[0] if prompt is not None else pre_c.shape[0]
         cfg_on = scaler.guidance_scale > 1
         passes = (3 if scaler.extra_pass else 2) if cfg_on else 1
         B = S0 // 2 if cfg_on else S0
@@ -439,7 +449,7 @@ class NovaEngine(object):
             return torch.stack([v.to(device=dev, dtype=dtype) for v in latents], dim=2)
 
         # ---- condition rows of every guidance pass: [cond ; uncond ; third] (guidance_scaler.py:46-57 expand_text)
-        prompt = prompt.to(device=dev, dtype=dtype)
+        prompt = None if prompt is None else prompt.to(device=dev, dtype=dtype)
         motion = None
         if m.motion_embed is not None and inputs.get("motion_flow", None) is not None:  # transformer_3d.py:72-75
             flow, fps = inputs.get("motion_flow"), inputs.get("fps", None)
@@ -449,7 +459,8 @@ class NovaEngine(object):
             motion = torch.tensor([flow, fps], dtype=_F32).t().contiguous()  # [S0, 2]
         if passes == 3:
             third = slice(B, 2 * B) if scaler.image_guidance_scale else slice(0, B)
-            prompt = torch.cat([prompt, prompt[third]])
+            prompt = None if prompt is None else torch.cat([prompt, prompt[third]])
+            pre_c = None if pre_c is None else torch.cat([pre_c, pre_c[third]])
             motion = torch.cat([motion, motion[third]]) if motion is not None else None
 
         # ---- random draws for the WHOLE batch, in the reference's order (embeddings.py:265; transformer_3d.py:131).
@@ -503,7 +514,8 @@ class NovaEngine(object):
             # a single lane stays on the caller's stream unless that is the legacy default stream, which cannot be
             # captured (nova_decoder_denoise replays its launch sequence as a hipGraph)
             stream = main if (lanes == 1 and main != torch.cuda.default_stream(dev)) else self._lane_stream(k)
-            ctx = dict(k=k, lo=lo, hi=hi, prompt=pick(prompt), motion=None if motion is None else pick(motion),
+            ctx = dict(k=k, lo=lo, hi=hi, prompt=None if prompt is None else pick(prompt), pre=None if pre_c is None else pick(pre_c),
+                       S=passes * (hi - lo), motion=None if motion is None else pick(motion),
                        order=order[lo:hi].contiguous(), stream=stream, inbox=None, frames=[],
                        first=None if first is None else first[lo:hi])
             runs.append((ctx, self._lane(ctx, inputs, T=T, passes=passes, timesteps=timesteps, coefs=coefs, ancestral=ancestral,
@@ -570,16 +582,24 @@ class NovaEngine(object):
         pk = self.misc
         cache = pk.__dict__.get("mixer", None)
         if cache is None:
-            lora = None if isinstance(mx.lora, torch.nn.Identity) else pk.w(mx.lora.weight, self.dtype)
-            cache = pk.mixer = (lora, mx.lora.weight.shape[0] if lora else 0, pk.w(mx.proj.weight, self.dtype), pk.f(mx.proj.bias))
             if not isinstance(mx.norm, torch.nn.Identity):
                 raise NotImplementedError("a normalising video mixer (eps != None) is not built on the HIP path")
+            if isinstance(mx.lora, torch.nn.Identity):
+                cache = pk.mixer = (None, 0, pk.w(mx.proj.weight, self.dtype), pk.f(mx.proj.bias))
+            else:
+                # low-rank pair proj(lora(.)) with nothing between the two: a rank that is not a multiple of the GEMM tile width is
+                # padded with zero rows of `lora` and zero columns of `proj` - the padded products are exact zeros, the result is unchanged
+                lw, pw_ = mx.lora.weight.detach(), mx.proj.weight.detach()
+                rank = lw.shape[0]
+                rank_p = -(-rank // 128) * 128
+                if rank_p != rank:
+                    lw = torch.cat([lw, lw.new_zeros(rank_p - rank, lw.shape[1])])
+                    pw_ = torch.cat([pw_, pw_.new_zeros(pw_.shape[0], rank_p - rank)], dim=1)
+                cache = pk.mixer = (pk.w(lw, self.dtype), rank_p, pk.w(pw_, self.dtype), pk.f(mx.proj.bias))
         lora, rank, pw, pb = cache
         act = torch.empty_like(cur)
         hip.call("nova_silu_add_rows", cur.data_ptr(), None, act.data_ptr(), cur.shape[0], self.D, self.code, hip.stream_ptr())
-        if lora:
-            if rank % 128:
-                raise NotImplementedError(f"video mixer rank {rank} is not a multiple of 128 (GEMM tile width)")
+        if lora is not None:
             act = self._gemm(act, lora, None, rank)
         mod = self._gemm(act, pw, pb, 2 * self.D)
         out = torch.empty_like(first)
@@ -600,15 +620,16 @@ class NovaEngine(object):
         pv = ve.patch_embed.patch_size
         hv, wv = H // pv, W // pv
         N, Nv, P, Pv = h * w, hv * wv, p * p * C, pv * pv * C
-        prompt = ctx["prompt"]
-        S, Lt = prompt.shape[0], prompt.shape[1]
+        prompt, pre = ctx["prompt"], ctx["pre"]
+        S, Lt = ctx["S"], (0 if prompt is None else prompt.shape[1])
+        Lc = 0 if pre is None else pre.shape[1]
         B = S // passes
         steps = len(timesteps)
         renorm = float(scaler.guidance_renorm)
         nmax = max(num_preds) if num_preds else 1
-        Lp = Lt + (2 if ctx["motion"] is not None else 0)  # condition prefix: text tokens (+ flow and fps tokens)
+        Lp = Lc + Lt + (2 if ctx["motion"] is not None else 0)  # condition prefix: given rows, text tokens, flow and fps tokens
         L2 = Nv + N
-        mod_bytes = steps * S * nmax * (3 * self.dec.depth + 2) * D * prompt.element_size()
+        mod_bytes = steps * S * nmax * (3 * self.dec.depth + 2) * D * torch.empty((), dtype=dtype).element_size()
         mod_steps = steps if (steps > 1 and mod_bytes <= self.MOD_HOIST_BYTES and not inputs.get("per_step_adaln", False)) else 1
         ws = self._workspace(S, B, N, max(L2, Lp + Nv), nmax, ctx["k"], mod_steps)
         # fp8 delayed-scaling state is per call: every generation starts from the documented first-step guess (64 / 448) and adapts
@@ -619,10 +640,13 @@ class NovaEngine(object):
         extra_scale = float(scaler.image_guidance_scale or scaler.spatiotemporal_guidance_scale) if passes == 3 else 0.0
 
         # ---- condition prefix: TextEmbed.forward (embeddings.py:203-206) [+ MotionEmbed tokens, transformer_3d.py:72-75]
-        pr = prompt.reshape(S * Lt, -1).contiguous()
-        c_txt = self._norm_rows(self._gemm(pr, self.text[0], self.text[1], D), self.text[2:])
+        parts = [] if pre is None else [pre]
+        if prompt is not None:
+            pr = prompt.reshape(S * Lt, -1).contiguous()
+            parts.append(self._norm_rows(self._gemm(pr, self.text[0], self.text[1], D), self.text[2:]).view(S, Lt, D))
         if ctx["motion"] is not None:
-            c_txt = torch.cat([c_txt.view(S, Lt, D), self._motion_tokens(ctx["motion"])], dim=1).reshape(S * Lp, D).contiguous()
+            parts.append(self._motion_tokens(ctx["motion"]))
+        c_txt = (parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)).reshape(S * Lp, D).contiguous()
         temb = ws["temb"].get(steps)
         if temb is None:
             temb = ws["temb"][steps] = torch.empty(steps, D, dtype=dtype, device=dev)

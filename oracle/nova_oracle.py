@@ -318,8 +318,11 @@ def make_config(image_dim, latent_hw, patch, embed_dim, heads, video_depth, imag
 def generate(p, cfg, prompt, num_preds, num_diffusion_steps=25, guidance_scale=5.0, generator=None,
              shift=1.0, dtype=torch.float32, u_dist=None, noises=None, trace=None, guidance_trunc=0, guidance_renorm=1,
              ddpm=None, max_latent_length=1, image_guidance_scale=0, spatiotemporal_guidance_scale=0, motion_flow=None,
-             fps=None, latents=None):
+             fps=None, latents=None, c_pre=None):
     """Transformer3DModel.forward in eval mode (transformer_3d.py:63-77,102-164,192-200).
+
+    c_pre: the caller's own condition list inputs["c"] (transformer_3d.py:66: model-width rows [S, Lc_i, D]; the text embedding of
+    `prompt` is appended behind them, :70-71; `prompt` None = no text rows, as when the model has no text embedding).
 
     prompt: [2B, Lt, token_dim] from encode_prompt_embeds ([B, ...] when guidance_scale <= 1). Returns x [B, C, T, H, W]
     with T = max_latent_length (a point set is T = 1).
@@ -338,12 +341,16 @@ def generate(p, cfg, prompt, num_preds, num_diffusion_steps=25, guidance_scale=5
     cfg_on = guidance_scale > 1
     extra_pass = image_guidance_scale + spatiotemporal_guidance_scale > 0
     passes = (3 if extra_pass else 2) if cfg_on else 1
-    B = prompt.shape[0] // 2 if cfg_on else prompt.shape[0]
+    rows0 = prompt.shape[0] if prompt is not None else c_pre[0].shape[0]
+    B = rows0 // 2 if cfg_on else rows0
     expand = (lambda t: torch.cat([t] * passes)) if cfg_on else (lambda t: t)
 
-    # preprocess :63-77 — TextEmbed.forward embeddings.py:203-206 (+ MotionEmbed :72-75)
-    c_txt = layer_norm(F.linear(prompt.to(dtype), p["text_embed.proj.weight"], p["text_embed.proj.bias"]),
-                       p["text_embed.norm.weight"], p["text_embed.norm.bias"])
+    # preprocess :63-77 — the given list, then TextEmbed.forward embeddings.py:203-206 (+ MotionEmbed :72-75), torch.cat(dim=1) :77
+    parts = [t.to(dtype) for t in (c_pre or [])]
+    if prompt is not None:
+        parts.append(layer_norm(F.linear(prompt.to(dtype), p["text_embed.proj.weight"], p["text_embed.proj.bias"]),
+                                p["text_embed.norm.weight"], p["text_embed.norm.bias"]))
+    c_txt = torch.cat(parts, dim=1) if len(parts) > 1 else parts[0]
     if motion_flow is not None and "motion_embed.flow_proj.0.weight" in p:
         flow = list(motion_flow) * (2 if cfg_on else 1)
         fps_rows = list(fps) * (2 if cfg_on else 1) if fps else None

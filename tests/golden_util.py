@@ -30,3 +30,11 @@ class Golden(object):
         return O.make_config(m["image_dim"], (m["latent_h"], m["latent_w"]), m["patch"], m["D"], m["heads"],
                              m["video_depth"], m["image_depth"], m["decoder_depth"], m["token_len"], bool(m["rotary"]),
                              video_base_t=m.get("T", 1))
+
+
+def c_rows_case():
+    """tests/golden/tiny_rope_c_rows.npz (make_golden_c_rows.py: the reference run with a caller-supplied condition list on the model of
+    tiny_rope.npz): (Golden("tiny_rope"), [rows_a, rows_b], {"out/x_rows_then_text": x, "out/x_rows_only": x})."""
+    z = np.load(os.path.join(GOLDEN_DIR, "tiny_rope_c_rows.npz"), allow_pickle=False)
+    rows = [torch.from_numpy(z[f"in/c_rows/{i}"]) for i in range(2)]
+    return Golden("tiny_rope"), rows, {k: torch.from_numpy(z[k]) for k in z.files if k.startswith("out/")}

@@ -697,6 +697,91 @@ def test_multi_frame_three_pass_at_full_width_matches_oracle(hip):
     assert torch.equal(from_gen[2], injected) and torch.equal(from_gen[1], injected)
 
 
+@pytest.mark.parametrize("rank", [48, 128])
+def test_low_rank_frame_mixer_matches_oracle(hip, rank):
+    """video_mixer_rank > 0 (normalization.py:33-36: proj(lora(SiLU(z))), transformer_nova.py:87-89): a rank that is no multiple of the
+    GEMM tile width runs on zero-padded lora rows / proj columns - exact zeros in the products - and one that is runs as it stands."""
+    from diffnext.models.transformers import transformer_nova as TN
+
+    D, heads, H, W, T = 128, 2, 8, 8, 2
+    TN.VIDEO_ENCODERS.register("m_vit_d1w128v", TN._vit, depth=1, embed_dim=D, num_heads=heads)
+    TN.IMAGE_ENCODERS.register("m_vit_d1w128i", TN._vit, depth=1, embed_dim=D, num_heads=heads)
+    TN.IMAGE_DECODERS.register("m_mlp_d1w128", TN._mlp, depth=1, embed_dim=D)
+    torch.manual_seed(23)
+    model = TN.NOVATransformer3DModel(image_dim=3, image_size=(H * 16, W * 16), image_stride=16, text_token_dim=64, text_token_len=8,
+                                      image_base_size=[H, W], video_base_size=[T, H // 2, W // 2], video_mixer_rank=rank,
+                                      rotary_pos_embed=True, arch=("m_vit_d1w128v", "m_vit_d1w128i", "m_mlp_d1w128")).eval()
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if n_.endswith("bias") or "mixer" in n_:
+                p_.add_(torch.randn_like(p_) * 0.05)
+    assert model.video_encoder.mixer.lora.weight.shape == (rank, D)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    prompts = [torch.randn(n, 64, generator=g) * 0.5 for n in (5, 3)]
+    cfg = O.make_config(3, (H, W), 1, D, heads, 1, 1, 1, 8, rotary=True, video_base_t=T)
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 8)
+    ref = O.generate(sd, cfg, prompt, O.cosine_schedule(H * W, 3), num_diffusion_steps=2, guidance_scale=4.0,
+                     generator=torch.Generator().manual_seed(9), max_latent_length=T, motion_flow=[5] * 2)
+    pipe = NOVAPipeline(transformer=model.cuda(), scheduler=FlowMatchEulerDiscreteScheduler())
+    x = pipe(prompt_embeds=[p.cuda() for p in prompts], generator=torch.Generator().manual_seed(9), num_inference_steps=3,
+             num_diffusion_steps=2, guidance_scale=4.0, max_latent_length=T, output_type="latent", disable_progress_bar=True,
+             motion_flow=5).frames
+    assert x.shape == ref.shape == (2, 3, T, H, W)
+    assert rel(x, ref) < 1e-4, rel(x, ref)
+
+
+@pytest.mark.parametrize("key,with_prompt", [("out/x_rows_then_text", True), ("out/x_rows_only", False)])
+def test_caller_supplied_condition_rows_match_reference(hip, key, with_prompt):
+    """inputs["c"] given by the caller against the REFERENCE's own run (tests/golden/tiny_rope_c_rows.npz, made by
+    make_golden_c_rows.py on the model of tiny_rope.npz): f32 on the GPU from the fixture's seed."""
+    from golden_util import c_rows_case
+
+    gold, rows, outs = c_rows_case()
+    m = gold.meta
+    model = build_from_golden(gold, torch.float32, "cuda")
+    model.sample_scheduler = FlowMatchEulerDiscreteScheduler()
+    inputs = dict(c=[r.cuda() for r in rows], num_preds=[int(v) for v in gold.t["in/num_preds"]], num_diffusion_steps=m["S"],
+                  guidance_scale=m["guidance"], generator=torch.Generator().manual_seed(m["sample_seed"]))
+    if with_prompt:
+        inputs["prompt"] = gold.t["in/prompt"].cuda()
+    x = model(inputs)["x"]
+    assert rel(x, outs[key]) < 1e-4
+
+
+@pytest.mark.parametrize("with_prompt", [True, False])
+def test_caller_supplied_condition_rows_match_oracle(hip, with_prompt):
+    """inputs["c"] given by the caller (transformer_3d.py:66: model-width rows, e.g. label embeddings - pipeline_nova_c2i.py:88): they
+    lead the condition prefix, the text embedding of the prompt follows (:70-71); without a prompt they are the whole prefix. HIP f32
+    against the oracle from the same seed; bf16 runs and two lanes give what one lane gives."""
+    model, sd, cfg = _tiny_model(128, 2, (6, 10), image_dim=3, stride=16, rotary=True, seed=17)
+    g = torch.Generator().manual_seed(31)
+    B = 3
+    prompts = [torch.randn(2 + i, 64, generator=g) * 0.5 for i in range(B)]
+    rows = [torch.randn(2 * B, 3, 128, generator=g) * 0.3, torch.randn(2 * B, 1, 128, generator=g) * 0.3]  # [cond ; uncond] rows, two list entries
+    model = model.cuda()
+    model.sample_scheduler = FlowMatchEulerDiscreteScheduler()
+    num_preds = O.cosine_schedule(60, 5)
+    inputs = lambda lanes: dict(c=[r.cuda() for r in rows], num_preds=list(num_preds), num_diffusion_steps=3, guidance_scale=4.0,
+                                generator=torch.Generator().manual_seed(6), lanes=lanes,
+                                **({"prompt": model.text_embed.encode_prompts([p.cuda() for p in prompts] + [torch.zeros(0, 64).cuda()] * B)} if with_prompt else {}))
+    out = model(inputs(2))["x"]
+    prompt = O.encode_prompt_embeds(sd["text_embed.weight"], prompts, 8) if with_prompt else None  # [padded prompts ; all-pad rows]
+    ref = O.generate(sd, cfg, prompt, num_preds, num_diffusion_steps=3, guidance_scale=4.0, generator=torch.Generator().manual_seed(6),
+                     c_pre=rows)
+    assert out.shape == ref.shape == (B, 3, 1, 6, 10)
+    assert rel(out, ref) < 1e-4
+    assert torch.equal(model(inputs(1))["x"], out)
+    other = O.generate(sd, cfg, prompt, num_preds, num_diffusion_steps=3, guidance_scale=4.0, generator=torch.Generator().manual_seed(6),
+                       c_pre=[rows[0]])
+    assert rel(other, ref) > 1e-3  # the rows matter
+    with pytest.raises(ValueError):
+        model(dict(inputs(1), c=[rows[0][:, :, :64].cuda()]))  # wrong width
+    if not with_prompt:
+        with pytest.raises(ValueError):
+            model(dict(num_preds=list(num_preds), guidance_scale=4.0))  # nothing to condition on
+
+
 def test_three_pass_rejects_both_scales(vgold, hip):
     with pytest.raises(ValueError):
         video_call(vgold, "cuda", torch.float32, image_guidance_scale=1.0, spatiotemporal_guidance_scale=1.0)

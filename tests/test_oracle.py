@@ -91,6 +91,22 @@ def test_guidance_trunc_and_renorm_match_reference(gold):
     assert (ref - gold.t["out/x"]).abs().max() > 1e-3 * ref.abs().max()  # the options really change the result
 
 
+@pytest.mark.parametrize("key,with_prompt", [("out/x_rows_then_text", True), ("out/x_rows_only", False)])
+def test_caller_supplied_condition_rows_match_reference(key, with_prompt):
+    """inputs["c"] given by the caller (transformer_3d.py:66-77), run by the reference on the model of tiny_rope.npz
+    (tests/golden/make_golden_c_rows.py): rows | TextEmbed(prompt) as the prefix, and the rows alone when there is no prompt."""
+    from golden_util import c_rows_case
+
+    gold, rows, outs = c_rows_case()
+    m = gold.meta
+    x = O.generate(gold.weights, gold.oracle_config(), gold.t["in/prompt"] if with_prompt else None, gold.t["in/num_preds"].numpy(),
+                   num_diffusion_steps=m["S"], guidance_scale=m["guidance"], generator=torch.Generator().manual_seed(m["sample_seed"]),
+                   c_pre=rows)
+    ref = outs[key]
+    assert x.shape == ref.shape and (x - ref).abs().max() <= 1e-5 * ref.abs().max()
+    assert (ref - gold.t["out/x"]).abs().max() > 1e-3 * ref.abs().max()  # the rows change the result
+
+
 def test_ddpm_plan_basics():
     plan = O.ddpm_plan(10, num_train_timesteps=100)
     assert [p[0] for p in plan] == list(range(90, -1, -10))
