@@ -155,9 +155,9 @@ template <typename OT>
 __device__ __forceinline__ void store8(OT* dst, f4v lo, f4v hi) {  // 8 consecutive columns of one row
   if constexpr (sizeof(OT) == 2) {
     const u4v pk = u4v{Half16<OT>::pack(lo[0], lo[1]), Half16<OT>::pack(lo[2], lo[3]), Half16<OT>::pack(hi[0], hi[1]), Half16<OT>::pack(hi[2], hi[3])};
-    // Streaming (`nt`) stores: a round of an XCD's 32 workgroups writes 4 MB of output through a 4 MB L2 that the same round's operand
-    // panels are being re-read from; marked streaming the output lines go first. 1.4-2.3 % on the K = 1024 launches, level at K = 4096,
-    // the LayerNorm pass that reads the result next is not slower (profiles/r04_gemm_nt_stores_ab.txt; -DNOVA_PLAIN_STORES: the A/B build)
+    // Streaming (`nt`) stores: 1.4-2.3 % on the K = 1024 launches, level at K = 4096, and the LayerNorm pass that reads the result next is
+    // not slower (profiles/r04_gemm_nt_stores_ab.txt; -DNOVA_PLAIN_STORES: the A/B build). The counters do not show why: L2 hit rate and
+    // fabric fetch per launch are the same with either policy (profiles/r04_pmc_table.md) - the gain is on the write path.
 #ifdef NOVA_PLAIN_STORES
     *reinterpret_cast<u4v*>(dst) = pk;
 #else
