@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NOVA_HIP_VERSION 400 /* 0.4.0 (round 4): the loader checks this number against its own; nova_attn_fwd_lse / nova_attn_bwd carry a key_limit pointer before the stream, nova_row_norm_bwd, nova_act_fwd, nova_act_bwd, nova_debug_drop_graphs (all added after 0.3.0 without a bump), nova_prof slots 7-9; 0.3.0: NOVA_F16 storage mode through every dtype-taking entry, nova_row_norm_chain takes a dtype, nova_debug_set_attn_variant; 0.2.2: nova_attn_fwd_lse, nova_attn_bwd; 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
+#define NOVA_HIP_VERSION 401 /* 0.4.1: nova_decoder_denoise_echo (guidance renorm with any sampler step); 0.4.0 (round 4): the loader checks this number against its own; nova_attn_fwd_lse / nova_attn_bwd carry a key_limit pointer before the stream, nova_row_norm_bwd, nova_act_fwd, nova_act_bwd, nova_debug_drop_graphs (all added after 0.3.0 without a bump), nova_prof slots 7-9; 0.3.0: NOVA_F16 storage mode through every dtype-taking entry, nova_row_norm_chain takes a dtype, nova_debug_set_attn_variant; 0.2.2: nova_attn_fwd_lse, nova_attn_bwd; 0.2.1: nova_adaln_fc1, nova_row_norm_chain (0.2.0: 3-pass guidance fields in nova_sampler_step, KV-cached block stack, nova_modulate_rows) */
 
 typedef enum { NOVA_F32 = 0, NOVA_BF16 = 1, NOVA_F16 = 2 } nova_dtype;
 typedef enum { NOVA_ACT_NONE = 0, NOVA_ACT_GELU_ERF = 1, NOVA_ACT_SILU = 2 } nova_act;
@@ -380,6 +380,18 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
                          const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
                          void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int mod_steps,
                          int dtype, void* stream);
+
+/* The same loop with guidance_renorm < 1 for ANY sampler step (the DDPM ancestral step of scheduling_ddpm.py:236-316: noise and a
+ * clamp act on the rows that merely echo x_t, so their squared norm is not a scalar that evolves by itself): the echo rows are
+ * carried explicitly and take every step beside the predicted ones (guidance_scaler.py:67-72 norms over all N rows; for an echo
+ * row every guidance pass returns x_t).
+ *   echo_rows  [B, Ne, P] f32 in/out: the Ne = N - n rows of each sample that are not predicted in this AR step (in: their x_T)
+ *   echo_noise [steps, B, Ne, P] f32 or NULL: their per-step gaussian rows (used where sigma != 0)
+ * Everything else as nova_decoder_denoise (ws_v as for renorm there). Launched directly (no graph replay: per-call noise). */
+int nova_decoder_denoise_echo(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
+                              const float* noise, float renorm, float* echo_rows, const float* echo_noise, int Ne, int steps, int S, int B,
+                              int n, int P, int D, void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v,
+                              int mod_steps, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

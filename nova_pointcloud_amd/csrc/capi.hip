@@ -472,7 +472,7 @@ namespace nova {
 static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
                                     const float* noise, float renorm, float* echo_energy, int steps, int S, int B, int n, int P, int D,
                                     void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v, int mod_steps,
-                                    int dtype, hipStream_t st) {
+                                    int dtype, hipStream_t st, float* echo_rows = nullptr, const float* echo_noise = nullptr, int Ne = 0) {
   const bool do_renorm = renorm < 1.0f;
   const size_t es = esize(dtype);
   const int depth = dec->depth;
@@ -496,8 +496,9 @@ static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, con
     NOVA_REQUIRE(sp.extra_kind >= 0 && sp.extra_kind <= 2, NOVA_ERR_ARG, "decoder_denoise: extra_kind must be 0, 1 or 2");
     const int passes = cfg ? (sp.extra_kind ? 3 : 2) : 1;
     NOVA_REQUIRE(S >= passes * B, NOVA_ERR_SHAPE, "decoder_denoise: step %d needs %d guidance passes but S = %d, B = %d", i, passes, S, B);
-    NOVA_REQUIRE(!(do_renorm && cfg) || (sp.kx == 0.f && sp.kv == 1.f && sp.cx == 1.f && sp.sigma == 0.f && sp.clip <= 0.f),
-                 NOVA_ERR_ARG, "decoder_denoise: guidance renorm is built for the flow-matching Euler step only");
+    NOVA_REQUIRE(!(do_renorm && cfg) || echo_rows || (sp.kx == 0.f && sp.kv == 1.f && sp.cx == 1.f && sp.sigma == 0.f && sp.clip <= 0.f),
+                 NOVA_ERR_ARG, "decoder_denoise: guidance renorm with a scalar echo energy holds for the flow-matching Euler step only "
+                 "(other samplers: nova_decoder_denoise_echo with the echo rows)");
     const int Se = passes * B;
     const long rows = (long)Se * n;
     if (hoist) {
@@ -525,7 +526,17 @@ static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, con
     }
     const void* head_in = ws_h;
     const float* nz = (noise && sp.sigma != 0.f) ? noise + (size_t)i * nP : nullptr;
-    if (do_renorm && cfg) {  // guidance_scaler.py:67-72: two small launches, norms over the whole sample
+    if (do_renorm && echo_rows) {  // any sampler step: the echo rows are carried explicitly (rowops.hip: renorm_step_kernel)
+      const float* enz = (echo_noise && sp.sigma != 0.f) ? echo_noise + (size_t)i * B * Ne * P : nullptr;
+      if (cfg) {
+        float* extra = passes == 3 ? ws_v + 2 * nP : nullptr;
+        NOVA_TRY(head_cfg_step(head_in, dec->head_w, dec->head_b, x, nullptr, ws_v, ws_v + nP, extra, B, n, P, D, sp, 1, dtype, st));
+        NOVA_TRY(renorm_step(x, ws_v, ws_v + nP, extra, nz, echo_rows, enz, B, n * P, Ne * P, sp, renorm, 0, st));
+      } else {
+        NOVA_TRY(head_cfg_step(head_in, dec->head_w, dec->head_b, x, nz, nullptr, nullptr, nullptr, B, n, P, D, sp, 0, dtype, st));
+        NOVA_TRY(renorm_step(nullptr, nullptr, nullptr, nullptr, nullptr, echo_rows, enz, B, n * P, Ne * P, sp, renorm, 1, st));
+      }
+    } else if (do_renorm && cfg) {  // guidance_scaler.py:67-72: two small launches, norms over the whole sample
       float* extra = passes == 3 ? ws_v + 2 * nP : nullptr;
       NOVA_TRY(head_cfg_step(head_in, dec->head_w, dec->head_b, x, nullptr, ws_v, ws_v + nP, extra, B, n, P, D, sp, 1, dtype, st));
       NOVA_TRY(renorm_euler(x, ws_v, ws_v + nP, extra, echo_energy, B, n, P, sp.c0, renorm, st));
@@ -670,6 +681,22 @@ int nova_decoder_denoise(const nova_decoder* dec, const void* zc, const void* te
   const hipError_t el = hipGraphLaunch(it->second, st);
   NOVA_REQUIRE(el == hipSuccess, NOVA_ERR_LAUNCH, "decoder_denoise: hipGraphLaunch failed: %s", hipGetErrorString(el));
   return 0;
+}
+
+int nova_decoder_denoise_echo(const nova_decoder* dec, const void* zc, const void* temb, float* x, const nova_sampler_step* sched,
+                              const float* noise, float renorm, float* echo_rows, const float* echo_noise, int Ne, int steps, int S, int B,
+                              int n, int P, int D, void* ws_a, void* ws_u, void* ws_h, void* ws_f, void* ws_g, void* ws_mod, float* ws_v,
+                              int mod_steps, int dtype, void* stream) {
+  NOVA_REQUIRE(!bad_dtype(dtype), NOVA_ERR_ARG, "decoder_denoise_echo: bad dtype %d", dtype);
+  NOVA_REQUIRE(dec && zc && temb && x && sched && ws_a && ws_u && ws_h && ws_f && ws_g && ws_mod, NOVA_ERR_ARG,
+               "decoder_denoise_echo: null pointer");
+  NOVA_REQUIRE(S == B || S == 2 * B || S == 3 * B, NOVA_ERR_SHAPE, "decoder_denoise_echo: S must be B, 2B or 3B");
+  NOVA_REQUIRE(dec->depth >= 1 && dec->blocks, NOVA_ERR_ARG, "decoder_denoise_echo: the decoder needs at least one block");
+  NOVA_REQUIRE(renorm < 1.0f && echo_rows && ws_v && Ne >= 0, NOVA_ERR_ARG,
+               "decoder_denoise_echo: for guidance_renorm < 1 with the echo rows given (else: nova_decoder_denoise)");
+  if (n == 0 || B == 0) return 0;
+  return decoder_denoise_launches(dec, zc, temb, x, sched, noise, renorm, nullptr, steps, S, B, n, P, D, ws_a, ws_u, ws_h, ws_f, ws_g, ws_mod,
+                                  ws_v, mod_steps, dtype, (hipStream_t)stream, echo_rows, echo_noise, Ne);
 }
 
 }  // extern "C"

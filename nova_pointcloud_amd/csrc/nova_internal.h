@@ -135,6 +135,8 @@ int head_cfg_step(const void* h, const void* w, const float* bias, float* x, con
 int scale_vector(float* v, int n, float f, hipStream_t st);
 int renorm_euler(float* x, const float* vhat, const float* cond, const float* extra, float* echo, int B, int n, int P, float dt,
                  float renorm, hipStream_t st);
+int renorm_step(float* x, const float* vhat, const float* cond, const float* extra, const float* noise, float* echo, const float* echo_noise,
+                int B, int nP, int eP, const SamplerStep& sp, float renorm, int echo_only, hipStream_t st);
 int kv_append(const void* qkv, void* cache, int S, int Lq, int D, long cap, long base, int dtype, hipStream_t st);
 int modulate_rows(const void* x, const void* mod, void* out, long rows, int D, int dtype, hipStream_t st);
 

@@ -625,6 +625,70 @@ __global__ __launch_bounds__(256) void renorm_euler_kernel(float* __restrict__ x
   }
 }
 
+// Guidance renormalisation for ANY sampler step (the ancestral DDPM step: the echo rows take noise and a clamp, so their squared
+// norm is no longer a scalar that evolves by itself): the rows that merely echo x_t are carried explicitly - echo[b][0:eP], updated
+// here with the same step as the predicted rows. For an echo row every guidance pass returns x_t, so v-hat = cond = x_t and the
+// `extra` term vanishes (guidance_scaler.py:74-87 on rows where the decoder scatters nothing: diffusion_mlp.py).
+//   ratio = clamp(sqrt((sum cond^2 + sum echo^2) / (sum vhat^2 + sum echo^2)), renorm, 1)         (guidance_scaler.py:67-72)
+//   predicted rows: v = ratio vhat + extra;  echo rows: v = ratio x_t;  both: x0 = clamp(kx x + kv v), x <- c0 x0 + cx x + sigma noise
+// echo_only != 0 (guidance switched off for this step, guidance_trunc): the predicted rows were stepped by head_cfg_step already, the
+// echo rows take the step with ratio 1. One block per sample, fixed summation order.
+__global__ __launch_bounds__(256) void renorm_step_kernel(float* __restrict__ x, const float* __restrict__ vhat, const float* __restrict__ cond,
+                                                         const float* __restrict__ extra, const float* __restrict__ noise,
+                                                         float* __restrict__ echo, const float* __restrict__ echo_noise, int nP, int eP,
+                                                         SamplerStep sp, float renorm, int echo_only) {
+  __shared__ float red[3][4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* eb = echo + (long)b * eP;
+  float ratio = 1.0f;
+  if (!echo_only) {
+    const float* vb = vhat + (long)b * nP;
+    const float* cb = cond + (long)b * nP;
+    float sv = 0.f, sc = 0.f, se = 0.f;
+    for (int i = threadIdx.x; i < nP; i += 256) {
+      sv += vb[i] * vb[i];
+      sc += cb[i] * cb[i];
+    }
+    for (int i = threadIdx.x; i < eP; i += 256) se += eb[i] * eb[i];
+    sv = wave_sum(sv);
+    sc = wave_sum(sc);
+    se = wave_sum(se);
+    if (lane == 0) { red[0][wv] = sv; red[1][wv] = sc; red[2][wv] = se; }
+    __syncthreads();
+    const float E = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const float nx = sqrtf((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) + E);
+    const float nc = sqrtf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) + E);
+    ratio = fminf(fmaxf(nc / nx, renorm), 1.0f);
+    __syncthreads();  // every thread has read the echo rows before any of them is overwritten below
+  }
+  auto step = [&](float xo, float v, const float* nz, long e) {
+    float x0 = sp.kx * xo + sp.kv * v;
+    if (sp.clip > 0.f) x0 = fminf(fmaxf(x0, -sp.clip), sp.clip);
+    float xn = sp.c0 * x0 + sp.cx * xo;
+    if (nz) xn += sp.sigma * nz[e];
+    return xn;
+  };
+  if (!echo_only) {
+    for (int i = threadIdx.x; i < nP; i += 256) {
+      const long e = (long)b * nP + i;
+      x[e] = step(x[e], ratio * vhat[e] + (extra ? extra[e] : 0.f), noise, e);
+    }
+  }
+  for (int i = threadIdx.x; i < eP; i += 256) {
+    const long e = (long)b * eP + i;
+    echo[e] = step(echo[e], ratio * echo[e], echo_noise, e);
+  }
+}
+
+int renorm_step(float* x, const float* vhat, const float* cond, const float* extra, const float* noise, float* echo, const float* echo_noise,
+                int B, int nP, int eP, const SamplerStep& sp, float renorm, int echo_only, hipStream_t st) {
+  ProfScope prof(PROF_DECODER, 0.0, st);
+  if (B <= 0 || (nP <= 0 && eP <= 0)) return 0;
+  if (!echo || (!echo_only && (!x || !vhat || !cond))) return set_error(NOVA_ERR_ARG, "renorm_step: null pointer");
+  hipLaunchKernelGGL(renorm_step_kernel, dim3(B), dim3(256), 0, st, x, vhat, cond, extra, noise, echo, echo_noise, nP, eP, sp, renorm, echo_only);
+  return check_launch("renorm_step");
+}
+
 __global__ void scale_vector_kernel(float* v, int n, float f) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] *= f;

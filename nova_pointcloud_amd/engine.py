@@ -439,8 +439,6 @@ class NovaEngine(object):
         rng_dev = "cpu" if host_rng else dev
         steps = inputs.get("num_diffusion_steps", 25)
         timesteps, coefs, ancestral = sampler_plan(m.sample_scheduler, steps)
-        if scaler.guidance_renorm < 1 and ancestral:
-            raise NotImplementedError("guidance_renorm < 1 with an ancestral sampler is not built on the HIP path")
         num_preds = [int(v) for v in inputs["num_preds"] if v > 0]
         latents = list(inputs.get("latents", []) or [])
         prefilled = bool(latents)  # first frame given (image-to-video): frame 0 is not generated (transformer_3d.py:159-160)
@@ -770,6 +768,25 @@ class NovaEngine(object):
                 if ancestral:
                     step_noise = torch.stack([torch.zeros(B, n, P, dtype=_F32, device=dev) if e is None else e.gather(1, idx)
                                               for e in extra]).contiguous()
+                if renorm < 1 and cfg_on and ancestral:
+                    # the rows that only echo x_t in the reference (guidance_scaler.py:67-72 takes its norms over all N rows) are carried
+                    # explicitly: the ancestral step adds noise to them too (scheduling_ddpm.py:303-312), so no scalar stands in for them
+                    rest = torch.ones(B, N, dtype=torch.bool, device=dev).scatter_(1, pred_ids.long(), False)
+                    ridx = rest.nonzero()[:, 1].view(B, N - n, 1).expand(-1, -1, P)
+                    echo_rows = nz.gather(1, ridx).contiguous()
+                    echo_noise = torch.stack([torch.zeros(B, N - n, P, dtype=_F32, device=dev) if e is None else e.gather(1, ridx)
+                                              for e in extra]).contiguous()
+                    ws_v = torch.empty(3 * B * n * P, dtype=_F32, device=dev)
+                    hip.call("nova_decoder_denoise_echo", ctypes.byref(self.dec.struct), zc.data_ptr(), temb.data_ptr(), x_n.data_ptr(), plan,
+                             hip.ptr(step_noise), renorm, echo_rows.data_ptr(), echo_noise.data_ptr(), N - n, steps, S, B, n, P, D,
+                             ws["da"].data_ptr(), ws["du"].data_ptr(), ws["dh"].data_ptr(), ws["df"].data_ptr(), ws["dg"].data_ptr(),
+                             ws["dmod"].data_ptr(), ws_v.data_ptr(), mod_steps, code, st())
+                    canvas.scatter_(1, idx, x_n)
+                    done += n
+                    if i == len(num_preds) - 1:
+                        ctx["frames"].append(canvas)
+                    yield i
+                    continue
                 if renorm < 1 and cfg_on:  # squared norm of the rows that only echo x_t in the reference (guidance_scaler.py:67-72)
                     # per-sample sums in float64: an f32 reduction's summation order follows the tensor's batch size (torch tiles it by shape),
                     # which would make a sample's result depend - at rounding level - on how many samples share its lane

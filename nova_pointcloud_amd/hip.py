@@ -99,6 +99,8 @@ SIGNATURES = {
     + [c_int] * 4 + [c_void_p],
     "nova_decoder_denoise": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p]
     + [c_int] * 6 + [c_void_p] * 7 + [c_int, c_int, c_void_p],
+    "nova_decoder_denoise_echo": [ctypes.POINTER(Decoder), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p]
+    + [c_int] * 7 + [c_void_p] * 7 + [c_int, c_int, c_void_p],
 }
 SIGNATURES["nova_prof_enable"] = [c_int]
 SIGNATURES["nova_debug_force_gemm_tile"] = [c_int]
@@ -117,7 +119,7 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 400  # == NOVA_HIP_VERSION of include/nova_hip.h (tests/test_abi.py compares the two)
+ABI_VERSION = 401  # == NOVA_HIP_VERSION of include/nova_hip.h (tests/test_abi.py compares the two)
 
 
 def load(check_device=True):

@@ -440,6 +440,29 @@ def test_f32_pipeline_ddpm_matches_oracle(gold, hip, pred_type):
     assert err < 1e-4, err
 
 
+@pytest.mark.parametrize("trunc", [0.0, 500.0])
+def test_f32_pipeline_ddpm_with_guidance_renorm_matches_oracle(gold, hip, trunc):
+    """guidance_renorm < 1 under the ancestral DDPM step (guidance_scaler.py:67-72 norms over all N rows; scheduling_ddpm.py:303-312 adds noise
+    to the rows that merely echo x_t as well): the echo rows are carried explicitly (nova_decoder_denoise_echo). f32 against the oracle from
+    one seed, with and without guidance truncation (steps below the threshold: no renorm, the echo rows still take the step); two lanes = one."""
+    from diffnext.schedulers import DDPMScheduler
+
+    m = gold.meta
+    kw = dict(num_train_timesteps=1000, beta_schedule="scaled_linear", beta_start=0.00085, beta_end=0.012, prediction_type="epsilon")
+    pipe = NOVAPipeline(transformer=build_from_golden(gold, torch.float32, "cuda"), scheduler=DDPMScheduler(**kw))
+    call = lambda renorm, lanes: pipe(prompt_embeds=gold.prompt_embeds, num_inference_steps=m["K"], num_diffusion_steps=5, guidance_scale=m["guidance"],
+                                      guidance_renorm=renorm, guidance_trunc=trunc, generator=torch.Generator().manual_seed(33), output_type="latent",
+                                      disable_progress_bar=True, lanes=lanes).frames
+    x = call(0.3, 1)
+    ref = O.generate(gold.weights, gold.oracle_config(), gold.t["in/prompt"], gold.t["in/num_preds"].numpy(), num_diffusion_steps=5,
+                     guidance_scale=m["guidance"], guidance_renorm=0.3, guidance_trunc=trunc, generator=torch.Generator().manual_seed(33), ddpm=kw)
+    assert rel(x, ref) < 1e-4, rel(x, ref)
+    # the renormalisation acts - weakly: the echo rows (N - n rows of x_t against n predicted ones) dominate both norms; less still with truncation
+    assert rel(call(1, 1), ref) > 3 * rel(x, ref)
+    if m["B"] > 1:
+        assert torch.equal(call(0.3, 2), x)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_two_lanes_equal_one_lane(hip, dtype):
     """Half-batch lanes on two streams are a scheduling choice only: bit-identical points for lanes = 1, 2 (and 3)."""
