@@ -70,7 +70,8 @@ __device__ __forceinline__ float sum_over_g(float x) {
 __device__ long long g_attn_clock[2 * 1024];
 #endif
 template <typename E, int HD, int NQB, bool LSE, bool SUMM, bool MASK = false>  // E: bf16_t / f16_t (same loads, LDS images and stores; MFMA form and pair packing differ)
-__global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16_m16(const E* __restrict__ q, const E* __restrict__ k,
+__global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16_m16(
+    const E* __restrict__ q, const E* __restrict__ k,
                                                                          const E* __restrict__ v, E* __restrict__ o,
                                                                          int Lq, int Lk, long q_rs, long kv_rs, long o_rs, float c,
                                                                          int heads, int nq, int rev, long kv_ss, float* __restrict__ lse,
@@ -198,15 +199,28 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
     const char* tv32 = tk32 + B_T32;
     // ---- S^T[key][q] - m: 4 key blocks x NQB query blocks, every K fragment feeds NQB MFMAs
     f4v st[NQB][4];
+    // The d-steps of TWO key blocks are interleaved (and the order prescribed to the scheduler), so that an MFMA never directly follows the one whose
+    // result it accumulates on (hipcc's own order put the two d-steps of a score block back to back, with wait states between); K fragment reads
+    // run two ahead of their MFMAs. + 0.4-0.6 % (profiles/r04_attn_weave_ab.txt, second part); same operations in the same order per score: bit-identical.
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
+    for (int kb2 = 0; kb2 < 4; kb2 += 2) {
 #pragma unroll
       for (int ds = 0; ds < NDS; ++ds) {
-        const u4v kf = ds < 2 ? *reinterpret_cast<const u4v*>(tk + kb * 2048 + (ds == 0 ? koff0 : koff1))
-                              : *reinterpret_cast<const u4v*>(tk32 + kb * 1024 + koff2);
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb)
-          st[qb][kb] = Half16<E>::mfma16(kf, qf[qb][ds], ds == 0 ? negm[qb] : st[qb][kb]);
+        for (int kk = 0; kk < 2; ++kk) {
+          const int kb = kb2 + kk;
+          const u4v kf = ds < 2 ? *reinterpret_cast<const u4v*>(tk + kb * 2048 + (ds == 0 ? koff0 : koff1))
+                                : *reinterpret_cast<const u4v*>(tk32 + kb * 1024 + koff2);
+#pragma unroll
+          for (int qb = 0; qb < NQB; ++qb)
+            st[qb][kb] = Half16<E>::mfma16(kf, qf[qb][ds], ds == 0 ? negm[qb] : st[qb][kb]);
+        }
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // K fragment reads run two ahead of the MFMAs that use them
+#pragma unroll
+      for (int i = 0; i < 2 * NDS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0);  // the NQB MFMAs of one K fragment
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one more read
       }
     }
     if constexpr (MASK) {  // every tile: keys at or past the query's limit (which is <= Lk) contribute nothing
@@ -259,11 +273,13 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
       }
     }
     u4v pb[NQB][2];
+    float psum[NQB];
 #pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-      float psum = 0.f;
+    for (int qb = 0; qb < NQB; ++qb) psum[qb] = 0.f;
+    // p = exp2(S - m) of the key-block pair kp, packed to 16 bits: the B operand of the P V product
+    auto exps = [&](int kp) {
 #pragma unroll
-      for (int kp = 0; kp < 2; ++kp) {
+      for (int qb = 0; qb < NQB; ++qb) {
         u4v packed;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
@@ -271,16 +287,14 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
           for (int j = 0; j < 2; ++j) {
             const float p0 = __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j]);
             const float p1 = __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j + 1]);
-            if (!SUMM) psum += p0 + p1;
+            if (!SUMM) psum[qb] += p0 + p1;
             packed[2 * h2 + j] = Half16<E>::pack(p0, p1);
           }
         pb[qb][kp] = packed;
       }
-      if (!SUMM) l_run[qb] += psum;
-    }
-    // ---- O^T[dv][q] += V^T[dv][key] P^T[key][q] (every V fragment feeds NQB MFMAs); SUMM: l += 1 P^T on the same pipe
-#pragma unroll
-    for (int kp = 0; kp < 2; ++kp) {
+    };
+    // O^T[dv][q] += V^T[dv][key] P^T[key][q] for the key-block pair kp (every V fragment feeds NQB MFMAs); SUMM: l += 1 P^T on the same pipe
+    auto pv = [&](int kp) {
 #pragma unroll
       for (int dvb = 0; dvb < NDVB; ++dvb) {
         const char* a0 = dvb < 4 ? tv + kp * 4096 + voff[dvb] : tv32 + kp * 2048 + voff[dvb];
@@ -294,6 +308,34 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb) lacc[qb] = Half16<E>::mfma16(ones, pb[qb][kp], lacc[qb]);
       }
+    };
+#ifndef NOVA_ATTN_NO_WEAVE
+    // The exponentials of the second key-block pair are woven into the P V MFMAs of the first (one MFMA, two exponentials, one pack,
+    // prescribed to the scheduler): left alone hipcc emits all 32 exponentials, then all 20 MFMAs, and a wave's vector and matrix work
+    // overlap only through the SIMD's other waves. Same operations on the same values: bit-identical. Measured (tools/ab_attn.py, one process,
+    // -DNOVA_ATTN_NO_WEAVE for the plain order): + 1-2 % at head_dim 64 (L = 2049 .. 2560), + 2.5-3.7 % at head_dim 96, level at L <= 1537;
+    // in the benchmark's pass 979-983 -> 999-1000 TFLOP/s on one box (profiles/r04_attn_weave_ab.txt). 137 instead of 122 registers at head_dim 64.
+    exps(0);
+    __builtin_amdgcn_sched_barrier(0);
+    exps(1);
+    pv(0);
+#pragma unroll
+    for (int i = 0; i < NQB * NDVB; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);  // two exponentials
+      __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // one pack
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pv(1);
+#else
+    exps(0);
+    exps(1);
+    pv(0);
+    pv(1);
+#endif
+    if (!SUMM) {
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) l_run[qb] += psum[qb];
     }
   };
 
