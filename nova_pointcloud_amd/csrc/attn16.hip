@@ -199,6 +199,43 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
     const char* tv32 = tk32 + B_T32;
     // ---- S^T[key][q] - m: 4 key blocks x NQB query blocks, every K fragment feeds NQB MFMAs
     f4v st[NQB][4];
+    u4v pb[NQB][2];
+    float psum[NQB];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) psum[qb] = 0.f;
+    // p = exp2(S - m) of the key-block pair kp, packed to 16 bits: the B operand of the P V product
+    auto exps = [&](int kp) {
+#pragma unroll
+      for (int qb = 0; qb < NQB; ++qb) {
+        u4v packed;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float p0 = __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j]);
+            const float p1 = __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j + 1]);
+            if (!SUMM) psum[qb] += p0 + p1;
+            packed[2 * h2 + j] = Half16<E>::pack(p0, p1);
+          }
+        pb[qb][kp] = packed;
+      }
+    };
+    // O^T[dv][q] += V^T[dv][key] P^T[key][q] for the key-block pair kp (every V fragment feeds NQB MFMAs); SUMM: l += 1 P^T on the same pipe
+    auto pv = [&](int kp) {
+#pragma unroll
+      for (int dvb = 0; dvb < NDVB; ++dvb) {
+        const char* a0 = dvb < 4 ? tv + kp * 4096 + voff[dvb] : tv32 + kp * 2048 + voff[dvb];
+        const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
+        const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(a0 + (dvb < 4 ? 2048 : 1024)));
+        const u4v vf = __builtin_bit_cast(u4v, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) ot[qb][dvb] = Half16<E>::mfma16(vf, pb[qb][kp], ot[qb][dvb]);
+      }
+      if (SUMM) {
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) lacc[qb] = Half16<E>::mfma16(ones, pb[qb][kp], lacc[qb]);
+      }
+    };
     // The d-steps of TWO key blocks are interleaved (and the order prescribed to the scheduler), so that an MFMA never directly follows the one whose
     // result it accumulates on (hipcc's own order put the two d-steps of a score block back to back, with wait states between); K fragment reads
     // run two ahead of their MFMAs. + 0.4-0.6 % (profiles/r04_attn_weave_ab.txt, second part); same operations in the same order per score: bit-identical.
@@ -220,7 +257,7 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
 #pragma unroll
       for (int i = 0; i < 2 * NDS; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, NQB, 0);  // the NQB MFMAs of one K fragment
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one more read
+        if (i < 2 * NDS - 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one more read
       }
     }
     if constexpr (MASK) {  // every tile: keys at or past the query's limit (which is <= Lk) contribute nothing
@@ -272,43 +309,6 @@ __global__ __launch_bounds__(256, (NQB == 2 && HD == 64) ? 3 : 2) void attn_bf16
         for (int kb = 0; kb < 4; ++kb) st[qb][kb] -= delta;
       }
     }
-    u4v pb[NQB][2];
-    float psum[NQB];
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) psum[qb] = 0.f;
-    // p = exp2(S - m) of the key-block pair kp, packed to 16 bits: the B operand of the P V product
-    auto exps = [&](int kp) {
-#pragma unroll
-      for (int qb = 0; qb < NQB; ++qb) {
-        u4v packed;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const float p0 = __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j]);
-            const float p1 = __builtin_amdgcn_exp2f(st[qb][2 * kp + h2][2 * j + 1]);
-            if (!SUMM) psum[qb] += p0 + p1;
-            packed[2 * h2 + j] = Half16<E>::pack(p0, p1);
-          }
-        pb[qb][kp] = packed;
-      }
-    };
-    // O^T[dv][q] += V^T[dv][key] P^T[key][q] for the key-block pair kp (every V fragment feeds NQB MFMAs); SUMM: l += 1 P^T on the same pipe
-    auto pv = [&](int kp) {
-#pragma unroll
-      for (int dvb = 0; dvb < NDVB; ++dvb) {
-        const char* a0 = dvb < 4 ? tv + kp * 4096 + voff[dvb] : tv32 + kp * 2048 + voff[dvb];
-        const bf4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)a0);
-        const bf4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf4v*)(a0 + (dvb < 4 ? 2048 : 1024)));
-        const u4v vf = __builtin_bit_cast(u4v, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) ot[qb][dvb] = Half16<E>::mfma16(vf, pb[qb][kp], ot[qb][dvb]);
-      }
-      if (SUMM) {
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) lacc[qb] = Half16<E>::mfma16(ones, pb[qb][kp], lacc[qb]);
-      }
-    };
 #ifndef NOVA_ATTN_NO_WEAVE
     // The exponentials of the second key-block pair are woven into the P V MFMAs of the first (one MFMA, two exponentials, one pack,
     // prescribed to the scheduler): left alone hipcc emits all 32 exponentials, then all 20 MFMAs, and a wave's vector and matrix work
