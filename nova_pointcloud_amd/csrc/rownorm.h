@@ -38,7 +38,7 @@ template <typename T> struct Chunk16 {
   __device__ __forceinline__ Raw packed() const {
     return u4v{Half16<T>::pack(v[0][0], v[0][1]), Half16<T>::pack(v[0][2], v[0][3]), Half16<T>::pack(v[1][0], v[1][1]), Half16<T>::pack(v[1][2], v[1][3])};
   }
-  __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<u4v*>(p) = packed(); }
+  __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<u4v*>(p) = packed(); }  // (streaming stores here: - 1.6 % on the big LayerNorm pass alone, nothing on its pair with the next GEMM: not taken, profiles/r04_gemm_nt_stores_ab.txt)
   __device__ __forceinline__ Chunk<T> rounded() const { return from_raw(packed()); }  // the values as they read back after store()
 };
 template <> struct Chunk<bf16_t> : Chunk16<bf16_t> {};

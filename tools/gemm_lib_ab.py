@@ -69,4 +69,12 @@ for tag, N, K, act in (("out-projection 163840 x 1024 x 1024", 1024, 1024, 0), (
                 lib.nova_row_norm(o_.data_ptr(), out_.data_ptr(), gam.data_ptr(), bet.data_ptr(), None, 0, -1, -1, -1, res_.data_ptr(), None, S * L, N, 1e-5, 1, st)
             return run
         ab("out-projection + LayerNorm/residual pass", pair)
+
+        def norm_then_qkv(lib):  # the pair the other way round: the LayerNorm pass, then the GEMM that reads its result (QKV of the next block)
+            def run():
+                lib.nova_row_norm(o_.data_ptr(), out_.data_ptr(), gam.data_ptr(), bet.data_ptr(), None, 0, -1, -1, -1, res_.data_ptr(), None, S * L, N, 1e-5, 1, st)
+                lib.nova_qkv_rope(out_.data_ptr(), w.data_ptr(), b.data_ptr(), rope.data_ptr(), qkv.data_ptr(), S, L, D, heads, 2, 1, st)
+            return run
+        ab("LayerNorm/residual pass + QKV + RoPE", norm_then_qkv)
+        ab("LayerNorm/residual pass alone", lambda lib: lambda: lib.nova_row_norm(o_.data_ptr(), out_.data_ptr(), gam.data_ptr(), bet.data_ptr(), None, 0, -1, -1, -1, res_.data_ptr(), None, S * L, N, 1e-5, 1, st))
     del a_, w_, o_
