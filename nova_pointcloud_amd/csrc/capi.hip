@@ -508,10 +508,19 @@ static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, con
       NOVA_TRY(gemm_bias_act(ws_a, dec->adaln_w, dec->adaln_b, ws_mod, (int)rows, (int)mod_ld, D, NOVA_ACT_NONE, dtype, st));
     }
     NOVA_TRY(patch_embed_rows(x, dec->patch_w, dec->patch_b, ws_u, Se, B, n, P, D, dtype, st));
+    // Per block: m1 (modulate -> h), fc1 + SiLU, fc2, m2 (gated norm + residual -> u). Where the small-M kernel does not take m1 + fc1 as one
+    // launch (more than ~320 rows: every step of the batch-32 workload but the first few), m2 of block b and m1 of block b + 1 are ONE row pass
+    // (row_norm_chain: u is written, h comes out of the same registers; bit-identical to the two launches), so a block is 3 launches instead of 4.
+    const bool m1_fused = gemm_modulate_fused((int)rows, D, D, dtype);  // m1 rides inside the fc1 launch (skinny.hip)
+    const bool chain = !m1_fused && dtype_is16(dtype);
     for (int b = 0; b < depth; ++b) {
       const nova_mlp_block& blk = dec->blocks[b];
       RowNormArgs m1{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, b * 3 * D, b * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
-      NOVA_TRY(gemm_modulate_act(m1, blk.fc1_w, blk.fc1_b, ws_f, (int)rows, D, D, NOVA_ACT_SILU, dtype, st));  // one launch at small M
+      if (chain && b > 0) {
+        NOVA_TRY(gemm_bias_act(ws_h, blk.fc1_w, blk.fc1_b, ws_f, (int)rows, D, D, NOVA_ACT_SILU, dtype, st));  // h: the previous block's chain launch
+      } else {
+        NOVA_TRY(gemm_modulate_act(m1, blk.fc1_w, blk.fc1_b, ws_f, (int)rows, D, D, NOVA_ACT_SILU, dtype, st));  // one launch at small M
+      }
       NOVA_TRY(gemm_bias_act(ws_f, blk.fc2_w, blk.fc2_b, ws_g, (int)rows, D, D, NOVA_ACT_NONE, dtype, st));
       RowNormArgs m2{ws_g, ws_u, blk.norm2_w, blk.norm2_b, ws_mod, mod_ld, -1, -1, b * 3 * D + 2 * D, ws_u, nullptr, rows, D, 1e-5f};
       RowNormArgs mf{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, depth * 3 * D, depth * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
@@ -519,6 +528,9 @@ static int decoder_denoise_launches(const nova_decoder* dec, const void* zc, con
         // last block: its gated norm + residual and the final layer's modulate in ONE row pass (x itself is not needed
         // any more, so it is neither written nor read back); bit-identical to the two launches (rownorm.h)
         NOVA_TRY(row_norm_chain(m2, mf, nullptr, dtype, st));
+      } else if (chain) {
+        RowNormArgs m1n{ws_u, ws_h, nullptr, nullptr, ws_mod, mod_ld, (b + 1) * 3 * D, (b + 1) * 3 * D + D, -1, nullptr, nullptr, rows, D, 1e-6f};
+        NOVA_TRY(row_norm_chain(m2, m1n, ws_u, dtype, st));  // u <- m2 in place (row-local), h <- m1 of the next block
       } else {
         NOVA_TRY(row_norm(m2, dtype, st));
         if (b == depth - 1) NOVA_TRY(row_norm(mf, dtype, st));

@@ -61,12 +61,18 @@ __device__ __forceinline__ Frag<T> lds_frag(const char* tile, int row, int chunk
 // F = MFMA fragments per wave and dimension: 4 -> the 128x128 tile described above; 2 -> a 64x64 tile (round 4) for the denoising
 // loop's launches at 1100 .. 4000 rows, where the 128 tile gives fewer workgroups than CUs and a workgroup's LDS-DMA rate, not the chip's,
 // sets the time: a quarter of the operand bytes per workgroup, four times the workgroups. Same MFMA, same k order: bit-identical.
+#ifndef NOVA_GEMM64_STAGES
+#define NOVA_GEMM64_STAGES 2  // K-tile ring depth of the 64 x 64 tile: 3, 4 and 5 measured SLOWER than 2 (tools/gemm64_stages_ab.py, profiles/r04_gemm64_stages_ab.txt)
+#endif
 template <typename T, int EPI, int F = 4>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                        T* __restrict__ C, int M, int N, int K, int ntm,
                                                        int ntn, GemmEpi e) {
   constexpr int BM = 32 * F, BN = 32 * F, TILE_BYTES = BM * ROWB, WT = 16 * F;  // tile, bytes of one operand tile, rows / columns per wave
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  // K-tile buffers: 2 (a 4-deep ring measured 5 % slower for the 128 tile; for the 64 tile, whose K-tile is only 8 MFMAs per wave, rings of 3 - 5 were
+  // 4 - 11 % slower as well: what hides a K-tile's load latency there is the number of workgroups a CU holds, and a deeper ring takes that away)
+  constexpr int NST = F == 2 ? NOVA_GEMM64_STAGES : 2;
+  __shared__ __attribute__((aligned(16))) char smem[NST * 2 * TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
 
@@ -122,15 +128,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const T* __restrict__ A, c
 #pragma unroll
     for (int j = 0; j < F; ++j) acc[i][j] = bv[i];
 
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nkt) stage(s, s);
   for (int kt = 0; kt < nkt; ++kt) {
-    // tile kt landed for this wave, then for all of them; buffer (kt+1)&1 free. The wait is explicit: whether the
+    // tile kt landed for this wave, then for all of them; the buffer of tile kt - 1 is free. The wait is explicit: whether the
     // compiler drains vmcnt for LDS-DMA before a barrier depends on what else it has in flight (with the bias loads
-    // ahead of the loop it stopped doing so).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
-    const char* ta = smem + (kt & 1) * 2 * TILE_BYTES;
+    // ahead of the loop it stopped doing so). With NST > 2 it is counted: the NST - 2 younger tiles (2 F requests each) stay in flight.
+    if constexpr (NST == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      const int young = min(NST - 2, nkt - 1 - kt);
+      if (young >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * 2 * F) : "memory");
+      else if (young == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * 2 * F) : "memory");
+      else if (young == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * 2 * F) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // NST > 2: the bare barrier - __syncthreads() carries a fence that drains every outstanding request (vmcnt(0)), i.e. the ring
+    if constexpr (NST == 2) __syncthreads();
+    else asm volatile("s_barrier" ::: "memory");
+    if (kt + NST - 1 < nkt) stage((kt + NST - 1) % NST, kt + NST - 1);
+    const char* ta = smem + (kt % NST) * 2 * TILE_BYTES;
     const char* tw = ta + TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -313,10 +331,14 @@ int gemm_bias_act(const void* A, const void* W, const float* bias, void* out, in
   return dispatch_dtype(dtype, [&](auto tag) { return launch_gemm<decltype(tag)>(A, W, out, M, N, K, act, e, st); });
 }
 
+// whether gemm_modulate_act takes this shape as ONE launch (the AdaLN modulate as the small-M kernel's prologue)
+bool gemm_modulate_fused(int M, int N, int K, int dtype) {
+  return dtype_is16(dtype) && (g_force_tile == 16 || (g_force_tile == 0 && skinny_gemm_fits(M, N, K, true)));
+}
+
 int gemm_modulate_act(const RowNormArgs& pro, const void* W, const float* bias, void* out, int M, int N, int K, int act,
                       int dtype, hipStream_t st) {
-  if (dtype_is16(dtype) && (g_force_tile == 16 || (g_force_tile == 0 && skinny_gemm_fits(M, N, K, true))))
-    return skinny_gemm(nullptr, W, bias, out, M, N, K, act, &pro, dtype, st);
+  if (gemm_modulate_fused(M, N, K, dtype)) return skinny_gemm(nullptr, W, bias, out, M, N, K, act, &pro, dtype, st);
   if (int rc = row_norm(pro, dtype, st)) return rc;
   return gemm_bias_act(pro.out, W, bias, out, M, N, K, act, dtype, st);
 }

@@ -97,6 +97,7 @@ int row_norm(const RowNormArgs& a, int dtype, hipStream_t st);
 
 // ---- skinny.hip: small-M GEMM (bf16 / f16, K in {768, 1024}), bit-identical to the tile kernels; optional AdaLN-modulate prologue
 bool skinny_gemm_fits(int M, int N, int K, bool modulate);
+bool gemm_modulate_fused(int M, int N, int K, int dtype);  // gemm.hip: modulate + GEMM taken as one launch
 int skinny_forced_row_blocks();  // the calling thread's current setting (part of the decoder graph key)
 void skinny_force_row_blocks(int rb);  // calling thread: 1 / 2 / 4 = rows per workgroup 16 / 32 / 64 for plain launches, 0 = by rule
 int skinny_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, int act,
