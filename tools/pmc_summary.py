@@ -176,7 +176,7 @@ def main():
         pc = lambda v: "-" if v is None else f"{100 * v:.1f} %"
         for k, r in kernels.items():
             shares = "-" if "active_any" not in r else f"{100 * r['active_any']:.0f} / {100 * r['wait_inst']:.0f} / {100 * r['wait_any']:.0f} %"
-            rows.append(f"| `{k}` | {r.get('duration_us', '-')} | {r.get('clock_ghz', '-')} | {pc(r.get('mfma_pipe_util'))} | {r.get('valu_per_mfma', '-')} | {shares} | "
+            rows.append(f"| `{k}` | {r.get('duration_us', '-')} | {r.get('clock_ghz', '-')} | {pc(r.get('mfma_pipe_util'))} | {r.get('valu_per_mfma', 'no MFMA') if r.get('mfma_pipe_util') else 'no MFMA'} | {shares} | "
                         f"{pc(r.get('l2_hit'))} | {r.get('fetch_over_operands', '-')} | {r.get('hbm_over_algorithmic', '-')} |")
         open(sys.argv[3], "w").write("\n".join(rows) + "\n")
 
