@@ -137,6 +137,7 @@ MFMA_FAMILIES = ("attention", "qkv_gemm_rope", "gemm_bias", "gemm_bias_wide_k", 
 
 
 def pmc_traffic(family, workload, fp8=False):
+    pmc_traffic.clock_ghz = None
     """HBM bytes per launch of the dominant kernel from the newest profiles/r*_pmc.json (tools/pmc_collect.sh +
     tools/pmc_summary.py: separate rocprofv3 --pmc passes; counters cannot be read from inside the process). The file
     records the sha256 of the kernel sources it was measured on: a stale file is reported as such, not used."""
@@ -164,6 +165,7 @@ def pmc_traffic(family, workload, fp8=False):
         note = f"profiles/{name}: {doc['shape']}; 2 x FETCH_SIZE + WRITE_SIZE of the {names[family]} launch, separate rocprofv3 --pmc passes"
         if rec.get("hbm_over_algorithmic") is not None:
             note += f"; {rec['hbm_over_algorithmic']} x the launch's algorithmic bytes"
+        pmc_traffic.clock_ghz = rec.get("clock_ghz")  # GRBM_GUI_ACTIVE / 8 / duration of the same passes (the chip lowers its clock under load)
         return rec.get("hbm_bytes"), note
     return None, "no profiles/r*_pmc.json"
 
@@ -350,6 +352,10 @@ def main():
                        "ranks_seen": ranks_seen, "process_group": (dist.get_backend() if distributed else "none")},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": mfma[dom]["rate"], "peak": peak,
                          "unit": "TFLOP/s", "frac": round(mfma[dom]["rate"] / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
+                         "clock_ghz_under_counters": pmc_traffic.clock_ghz,
+                         "clock_note": "shader clock the chip held under this kernel in the rocprofv3 counter passes (GRBM_GUI_ACTIVE / 8 / duration; "
+                                       "nominal 2.4 GHz, which `peak` is priced at); in-kernel clock reads of every encoder kernel, on random and on "
+                                       "zero-filled operands: profiles/r04_kernel_clock.txt (not measured in this run)",
                          "avg_launch_ms": round(mfma[dom]["ms"] / mfma[dom]["launches"], 4),
                          "share_of_step_time": mfma[dom]["share"],
                          "kernel_choice": "family with the most time in the serialised pass; ties within 2 % go to the lower fraction",
