@@ -37,6 +37,9 @@
 // Epilogue: bias (the accumulators start at it), GELU / SiLU / RoPE pair rotation / q-scale lane-local on the lane's 4
 // consecutive columns, as in gemm.hip. Results are bit-identical to gemm.hip: tests/test_gpu_kernels.py compares them.
 #include <type_traits>
+#ifndef NOVA_GEMM_ACT_ROWS
+#define NOVA_GEMM_ACT_ROWS 1  // 0: all activations of a tile, then all its stores (A/B build)
+#endif
 #include "common.h"
 #include "nova_internal.h"
 
@@ -993,7 +996,9 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
     // The elementwise epilogues run IN PLACE on the accumulators, one register quad (4 rows of one column) at a time: the packed
     // f32 forms (v_pk_mul / v_pk_fma, gelu_erf_fast4) take aligned register pairs, and applied to the per-row gathers of the
     // stores below they cost one v_mov per operand pair on top (194 moves in 1096 vector instructions of the fc1 epilogue).
-    if constexpr (EPI == E_GELU || EPI == E_SILU) {
+    // (activations: applied row block by row block beside the stores, see act_rows below)
+    constexpr bool ACT_ROWS = NOVA_GEMM_ACT_ROWS && (EPI == E_GELU || EPI == E_SILU) && COLS8 && !TDMA;
+    if constexpr ((EPI == E_GELU || EPI == E_SILU) && !ACT_ROWS) {
 #pragma unroll
       for (int y = 0; y < 4; ++y)
 #pragma unroll
@@ -1061,6 +1066,17 @@ __global__ __launch_bounds__(512, 2) void gemm256c_kernel(const T* __restrict__ 
         else passes(std::false_type{});
       } else {
         plain_rows();
+      }
+    } else if constexpr (ACT_ROWS) {
+      // GELU / SiLU one 16-row block at a time, its four stores right behind it: the memory pipeline works the stores off while the vector
+      // pipe is on the next block's activation (hipcc's own order: all 128 exponentials and reciprocals, then all 16 stores)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) acc[y][x] = epi_apply<OT, EPI, false>(acc[y][x], acc[y][x], 1.0f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put8(y, r, value4(y, r, 0), value4(y, r, 1));
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else if constexpr (COLS8) {
       plain_rows();
